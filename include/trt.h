@@ -1,0 +1,188 @@
+/*
+ * trt.h — C ABI of the MI355X-native toroidal ray tracer (libtrt.so).
+ *
+ * This is the drop-in boundary for ONE path of raffaelecicellini/toroidal_ray_tracing:
+ * the ray-tracing dispatch `HelloVulkan::raytrace(cmdBuf, clearColor)` and the shader
+ * binding contract behind it.  Paths below are relative to
+ * vk_raytracing_tutorial_KHR/ in the reference (REFL = ray_tracing_reflections,
+ * BEF = ray_tracing__before).
+ *
+ *   reference interface                                  replaced by
+ *   ---------------------------------------------------  ----------------------------
+ *   HelloVulkan::raytrace          REFL/hello_vulkan.cpp:913-935,
+ *                                  BEF/hello_vulkan.cpp:936-958          trt_render*
+ *   raygen binding contract        REFL/shaders/raytrace.rgen:30-35,
+ *                                  BEF/shaders/raytrace.rgen:10-17       trt_globals/trt_push/outputs
+ *   traceRayEXT closest/any hit    REFL/shaders/raytrace.rgen:64-75,
+ *                                  REFL/shaders/raytrace.rchit:208-219   trt_trace*
+ *   TLAS + ObjDesc + materials     REFL/hello_vulkan.cpp:645-683,264-273 trt_scene
+ *   RenderedData SSBO              BEF/shaders/host_device.h:101-107     trt_rendered_data
+ *
+ * Plain C types only: pointers, sizes, PODs.  No exceptions cross this boundary; every
+ * entry point returns 0 (TRT_OK) or a negative TRT_E_* code and trt_last_error() holds
+ * the message.  There is NO CPU fallback inside the library: without a usable HIP
+ * device trt_create() fails with TRT_E_NO_DEVICE.
+ */
+#ifndef TRT_H_
+#define TRT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRT_VERSION_MAJOR 0
+#define TRT_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------------------ */
+enum {
+  TRT_OK            = 0,
+  TRT_E_INVALID     = -1, /* NULL / out-of-range argument                               */
+  TRT_E_NO_DEVICE   = -2, /* no HIP device / device index out of range                  */
+  TRT_E_HIP         = -3, /* a HIP runtime call failed (message has hipGetErrorString)  */
+  TRT_E_SCENE       = -4, /* scene rejected: >TRT_MAX_TORI, bad matId, not a ring torus */
+  TRT_E_NOMEM       = -5  /* device or host allocation failed                           */
+};
+
+#define TRT_MAX_TORI      8 /* BASELINE config 4: "8 nested tori (tokamak shells)"       */
+#define TRT_MAX_MATERIALS 8
+
+/* ---- camera models ----------------------------------------------------------------- */
+enum {
+  TRT_CAMERA_PINHOLE  = 0, /* REFL/shaders/raytrace.rgen:42-48                          */
+  TRT_CAMERA_TOROIDAL = 1  /* BEF/shaders/raytrace.rgen:21-57                           */
+};
+
+/* ---- solver precision (BASELINE config 4: "FP64 root solve", FP32 I/O) ------------- */
+enum { TRT_SOLVE_F32 = 0, TRT_SOLVE_F64 = 1 };
+
+/* ---- uniform / push-constant blocks, byte-for-byte the reference's host structs ---- */
+
+/* GlobalUniforms, BEF/shaders/host_device.h:69-75 (REFL/…:67-72 is the same without
+ * `center`).  mat4 is column-major (nvmath::mat4f / GLSL): element (row r, col c) is
+ * m[c*4 + r]. */
+typedef struct trt_globals {
+  float viewProj[16];
+  float viewInverse[16];
+  float projInverse[16];
+  float center[3]; /* camera look-at point; used by the toroidal camera only          */
+} trt_globals;      /* 204 bytes                                                        */
+
+/* PushConstantRay, BEF/shaders/host_device.h:90-98 (REFL/…:86-93 lacks `rho`). */
+typedef struct trt_push {
+  float   clearColor[4];
+  float   lightPosition[3];
+  float   lightIntensity;
+  int32_t lightType; /* 0 = point, otherwise directional (REFL rchit:81-91)             */
+  int32_t maxDepth;  /* bounce-loop bound, REFL/shaders/raytrace.rgen:79                */
+  float   rho;       /* toroidal camera: radius of the ray-origin circle                */
+} trt_push;          /* 44 bytes                                                        */
+
+/* WaveFrontMaterial, REFL/shaders/host_device.h:103-115 (scalar block layout). */
+typedef struct trt_material {
+  float   ambient[3];
+  float   diffuse[3];
+  float   specular[3];
+  float   transmittance[3];
+  float   emission[3];
+  float   shininess;
+  float   ior;
+  float   dissolve;
+  int32_t illum;
+  int32_t textureId; /* must be -1: tori are untextured (REFL rchit:100)                */
+} trt_material;      /* 80 bytes                                                        */
+
+/* One analytic torus: centre C, symmetry axis +y (the reference's world-up,
+ * REFL/main.cpp:95), major radius R, tube radius r, 0 < r < R.  Replaces one TLAS
+ * instance + its ObjDesc (REFL/shaders/host_device.h:57-64). */
+typedef struct trt_torus {
+  float   center[3];
+  float   R;
+  float   r;
+  int32_t matId;
+} trt_torus; /* 24 bytes */
+
+typedef struct trt_scene {
+  const trt_torus*    tori;
+  uint32_t            n_tori;      /* 1..TRT_MAX_TORI      */
+  const trt_material* materials;
+  uint32_t            n_materials; /* 1..TRT_MAX_MATERIALS */
+} trt_scene;
+
+/* RenderedData, BEF/shaders/host_device.h:101-107; written at index x*H + y
+ * (BEF/shaders/raytrace.rgen:72-73,111-112). */
+typedef struct trt_rendered_data {
+  float pos[4];
+  float color[4];
+  float rayOrigin[4];
+  float rayDir[4];
+} trt_rendered_data; /* 64 bytes */
+
+/* ---- ray / hit streams, structure-of-arrays ---------------------------------------- */
+typedef struct trt_rays {
+  const float* ox; const float* oy; const float* oz; /* origins                        */
+  const float* dx; const float* dy; const float* dz; /* directions, any non-zero length */
+  uint64_t     n;
+} trt_rays;
+
+/* Miss: t = +INFINITY, P = N = 0 (BEF/shaders/raytrace.rmiss:21), id = -1.
+ * Any pointer may be NULL to skip that stream. */
+typedef struct trt_hits {
+  float* t;
+  float* px; float* py; float* pz; /* hit point  O + t·D  (BEF rchit:134)               */
+  float* nx; float* ny; float* nz; /* outward unit normal, never flipped (REFL rchit:74-75) */
+  int32_t* id;                     /* index of the torus hit                            */
+} trt_hits;
+
+/* Per-frame query counters (one "test" = one ray against one torus). */
+typedef struct trt_stats {
+  uint64_t primary_tests;
+  uint64_t bounce_tests;
+  uint64_t shadow_tests;
+  uint64_t pixels;
+} trt_stats;
+
+typedef struct trt_ctx trt_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int         trt_version(void);                       /* MAJOR*1000 + MINOR               */
+int         trt_create(int device, trt_ctx** out);   /* one ctx per device, not re-entrant */
+void        trt_destroy(trt_ctx* ctx);
+const char* trt_last_error(const trt_ctx* ctx);      /* ctx may be NULL: create errors   */
+int         trt_set_solver(trt_ctx* ctx, int precision); /* TRT_SOLVE_F32 | TRT_SOLVE_F64 */
+
+/* ---- trace(rays_in -> hits_out): closest hit of every ray against the scene -------- */
+/* Host buffers: copies in, launches, copies out, synchronises. */
+int trt_trace(trt_ctx* ctx, const trt_rays* in, const trt_scene* scene,
+              float tmin, float tmax, trt_hits* out);
+/* Device-resident buffers, asynchronous on `stream` (a hipStream_t; NULL = default). */
+int trt_trace_dev(trt_ctx* ctx, const trt_rays* in_dev, const trt_scene* scene,
+                  float tmin, float tmax, trt_hits* out_dev, void* stream);
+
+/* ---- render: the faithful equivalent of HelloVulkan::raytrace ---------------------- */
+/* rgba_out: W*H*4 floats, row-major, image[y][x] = (hitValue, 1)  (rgen:87).
+ * first_hit_out: optional SoA record of the depth-0 hit per pixel, row-major y*W+x. */
+int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
+               uint32_t W, uint32_t H, int camera, float* rgba_out, trt_hits* first_hit_out);
+/* Rows [row_begin,row_end) only; outputs are indexed relative to the FULL image, so a
+ * rank that owns a row band passes pointers to the full-frame buffers (or to buffers
+ * offset by -row_begin*W elements).  rendered_dev is optional (BEF RenderedData, x*H+y). */
+int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
+                   uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, int camera,
+                   float* rgba_dev, trt_hits* first_hit_dev, trt_rendered_data* rendered_dev,
+                   void* stream);
+
+/* Counters of the last render or trace call made with counting enabled. */
+int trt_enable_stats(trt_ctx* ctx, int on);
+int trt_get_stats(trt_ctx* ctx, trt_stats* out); /* synchronises the ctx's last stream   */
+
+/* Name of the kernel variant used by trt_render* ("persistent" | "static"). */
+int         trt_set_render_variant(trt_ctx* ctx, const char* name);
+const char* trt_get_render_variant(const trt_ctx* ctx);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* TRT_H_ */

@@ -1,0 +1,579 @@
+/*
+ * trt_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement of the ray-tracing path of raffaelecicellini/toroidal_ray_tracing
+ * (paths relative to vk_raytracing_tutorial_KHR/; REFL = ray_tracing_reflections,
+ * BEF = ray_tracing__before).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; libtrt.so never does.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference cannot be built or run here (Vulkan RT
+ * + Windows + absent nvpro_core), it has no CPU path, no tests and no
+ * golden vectors, and it contains no ray–torus arithmetic at all.  What this file pins is
+ *   - the control flow / payload / shading semantics of the reference's GLSL, restated
+ *     line by line below with file:line citations, and
+ *   - build-defined torus arithmetic (trt_solve.inc), checked against analytic
+ *     known-answer vectors and an independent FP64 solver (oracle/truth.py).
+ *
+ * Arithmetic contract shared with the HIP kernels (so that they can agree bit for bit):
+ *   FP32 throughout; dot3(a,b) = fma(az,bz, fma(ay,by, ax*bx)); normalize(v) =
+ *   v * (1/sqrt(dot3(v,v))); mat4·vec4 accumulates columns 0,1,2,3 with fma; no implicit
+ *   contraction (-ffp-contract=off).  Only pow() (specular lobe) and the toroidal camera's
+ *   per-frame/per-column/per-row cos/sin/acos come from libm.
+ */
+#include "../include/trt.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* type-generic torus solver, instantiated for float and double                          */
+/* ------------------------------------------------------------------------------------ */
+#define REAL float
+#define SUF(x) x##_f32
+#define FMA fmaf
+#define SQRT sqrtf
+#define FMAX fmaxf
+#define FMIN fminf
+#define FABS fabsf
+#include "trt_solve.inc"
+#undef REAL
+#undef SUF
+#undef FMA
+#undef SQRT
+#undef FMAX
+#undef FMIN
+#undef FABS
+
+#define REAL double
+#define SUF(x) x##_f64
+#define FMA fma
+#define SQRT sqrt
+#define FMAX fmax
+#define FMIN fmin
+#define FABS fabs
+#include "trt_solve.inc"
+#undef REAL
+#undef SUF
+#undef FMA
+#undef SQRT
+#undef FMAX
+#undef FMIN
+#undef FABS
+
+/* ------------------------------------------------------------------------------------ */
+/* small FP32 vector helpers (GLSL built-ins restated)                                   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { float x, y, z; } v3;
+
+static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 sub3(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static inline v3 scale3(v3 a, float s) { v3 r = {a.x * s, a.y * s, a.z * s}; return r; }
+static inline v3 neg3(v3 a) { v3 r = {-a.x, -a.y, -a.z}; return r; }
+static inline v3 normalize3(v3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
+/* GLSL reflect(I,N) = I - 2·dot(N,I)·N */
+static inline v3 reflect3(v3 i, v3 n)
+{
+  const float k = 2.0f * dot3(n, i);
+  v3 r = {fmaf(-k, n.x, i.x), fmaf(-k, n.y, i.y), fmaf(-k, n.z, i.z)};
+  return r;
+}
+/* column-major mat4 · (x,y,z,w), rows 0..2 */
+static inline v3 mat4_mul(const float* m, float x, float y, float z, float w)
+{
+  v3 r;
+  r.x = fmaf(m[12], w, fmaf(m[8], z, fmaf(m[4], y, m[0] * x)));
+  r.y = fmaf(m[13], w, fmaf(m[9], z, fmaf(m[5], y, m[1] * x)));
+  r.z = fmaf(m[14], w, fmaf(m[10], z, fmaf(m[6], y, m[2] * x)));
+  return r;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* scene                                                                                 */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  int          n;
+  trt_torus    tori[TRT_MAX_TORI];
+  torus_k_f32  k32[TRT_MAX_TORI];
+  torus_k_f64  k64[TRT_MAX_TORI];
+  int          nmat;
+  trt_material mat[TRT_MAX_MATERIALS];
+  int          f64;
+} scene_t;
+
+static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
+{
+  if(!s || !s->tori || !s->materials || s->n_tori < 1 || s->n_tori > TRT_MAX_TORI
+     || s->n_materials < 1 || s->n_materials > TRT_MAX_MATERIALS)
+    return TRT_E_SCENE;
+  out->n    = (int)s->n_tori;
+  out->nmat = (int)s->n_materials;
+  out->f64  = precision == TRT_SOLVE_F64;
+  for(int i = 0; i < out->n; ++i)
+  {
+    const trt_torus* t = &s->tori[i];
+    if(!(t->r > 0.0f && t->R > t->r) || t->matId < 0 || t->matId >= out->nmat)
+      return TRT_E_SCENE;
+    out->tori[i] = *t;
+    torus_prepare_f32(t, &out->k32[i]);
+    torus_prepare_f64(t, &out->k64[i]);
+  }
+  memcpy(out->mat, s->materials, sizeof(trt_material) * (size_t)out->nmat);
+  return TRT_OK;
+}
+
+/* One ray against one torus, in the scene's solver precision; result rounded to FP32. */
+static inline int torus_hit(const scene_t* S, int i, v3 o, v3 d, float dd, float inv_dd,
+                            float tmin, float tmax, float* t, uint64_t* tests)
+{
+  ++*tests;
+  if(S->f64)
+  {
+    const double o64[3] = {o.x, o.y, o.z}, d64[3] = {d.x, d.y, d.z};
+    const double dd64   = fma(d64[2], d64[2], fma(d64[1], d64[1], d64[0] * d64[0]));
+    double       t64;
+    if(!torus_first_hit_f64(o64, d64, dd64, 1.0 / dd64, (double)tmin, (double)tmax, &S->k64[i],
+                            &t64, NULL))
+      return 0;
+    const float tf = (float)t64;
+    if(!(tf > tmin && tf < tmax)) /* rounding to FP32 may land on the open bounds */
+      return 0;
+    *t = tf;
+    return 1;
+  }
+  const float o32[3] = {o.x, o.y, o.z}, d32[3] = {d.x, d.y, d.z};
+  return torus_first_hit_f32(o32, d32, dd, inv_dd, tmin, tmax, &S->k32[i], t, NULL);
+}
+
+/* Closest hit over all tori (role of traceRayEXT + BVH, REFL/shaders/raytrace.rgen:64-75):
+ * smallest t, first torus wins ties.  Returns torus index or -1. */
+static int closest_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, float* t_out,
+                       uint64_t* tests)
+{
+  const float dd = dot3(d, d), inv_dd = 1.0f / dd;
+  int   id   = -1;
+  float best = INFINITY;
+  for(int i = 0; i < S->n; ++i)
+  {
+    float t;
+    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, &t, tests) && t < best)
+    {
+      best = t;
+      id   = i;
+    }
+  }
+  *t_out = best;
+  return id;
+}
+
+/* Any hit (gl_RayFlagsTerminateOnFirstHitEXT shadow query, REFL/shaders/raytrace.rchit:206-219). */
+static int any_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, uint64_t* tests)
+{
+  const float dd = dot3(d, d), inv_dd = 1.0f / dd;
+  for(int i = 0; i < S->n; ++i)
+  {
+    float t;
+    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, &t, tests))
+      return 1;
+  }
+  return 0;
+}
+
+/* T4: outward unit normal at P on torus i — N = normalize(P - q), q the nearest point of
+ * the centre circle (role of REFL/shaders/raytrace.rchit:74-75; never flipped). */
+static v3 torus_normal(const scene_t* S, int i, v3 P)
+{
+  const trt_torus* T = &S->tori[i];
+  const v3    c   = {T->center[0], T->center[1], T->center[2]};
+  const v3    pl  = sub3(P, c);
+  const float rho = sqrtf(fmaf(pl.z, pl.z, pl.x * pl.x));
+  const float k   = (rho - T->R) / rho;
+  const v3    v   = {pl.x * k, pl.y, pl.z * k};
+  return normalize3(v);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Phong helpers — REFL/shaders/wavefront.glsl:22-48                                      */
+/* ------------------------------------------------------------------------------------ */
+static v3 compute_diffuse(const trt_material* m, v3 L, v3 N)
+{
+  const float dotNL = fmaxf(dot3(N, L), 0.0f);                                 /* :25 */
+  v3 c = {m->diffuse[0] * dotNL, m->diffuse[1] * dotNL, m->diffuse[2] * dotNL}; /* :26 */
+  if(m->illum >= 1)                                                            /* :27 */
+  {
+    c.x += m->ambient[0];
+    c.y += m->ambient[1];
+    c.z += m->ambient[2];
+  }
+  return c;
+}
+
+static v3 compute_specular(const trt_material* m, v3 viewDir, v3 L, v3 N)
+{
+  v3 z = {0.0f, 0.0f, 0.0f};
+  if(m->illum < 2)                                                             /* :34 */
+    return z;
+  const float kPi        = 3.14159265f;                                        /* :38 */
+  const float kShininess = fmaxf(m->shininess, 4.0f);                          /* :39 */
+  const float kEnergy    = (2.0f + kShininess) / (2.0f * kPi);                 /* :42 */
+  const v3    V          = normalize3(neg3(viewDir));                          /* :43 */
+  const v3    R          = reflect3(neg3(L), N);                               /* :44 */
+  const float s          = kEnergy * powf(fmaxf(dot3(V, R), 0.0f), kShininess); /* :45 */
+  v3 r = {m->specular[0] * s, m->specular[1] * s, m->specular[2] * s};         /* :47 */
+  return r;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ray generation                                                                        */
+/* ------------------------------------------------------------------------------------ */
+#define TRT_DEG2RAD 0.017453292519943295f /* GLSL radians() */
+#define TRT_RAD2DEG 57.29577951308232f    /* GLSL degrees() */
+
+/* Per-frame part of the toroidal camera: BEF/shaders/raytrace.rgen:36-53. */
+typedef struct { v3 eye; float omega, theta; } toro_frame;
+
+static toro_frame toroidal_frame(const trt_globals* g, const trt_push* pc)
+{
+  toro_frame F;
+  F.eye         = mat4_mul(g->viewInverse, 0.0f, 0.0f, 0.0f, 1.0f);           /* :36 */
+  const v3 ctr  = {g->center[0], g->center[1], g->center[2]};
+  v3       temp = sub3(ctr, F.eye);                                            /* :38 */
+  float    il   = 1.0f / sqrtf(fmaf(temp.z, temp.z, temp.x * temp.x));         /* :39 */
+  float    dirx = temp.x * il;
+  F.omega       = acosf(dirx) * TRT_RAD2DEG;                                   /* :40 dot((1,0),dir) = dir.x */
+  if(temp.z < 0.0f)                                                            /* :41 */
+    F.omega = 360.0f - F.omega;
+  F.theta = 0.0f;
+  if(F.eye.y != ctr.y)                                                         /* :45 */
+  {
+    const float w = F.omega * TRT_DEG2RAD;
+    v3 p = {fmaf(pc->rho, cosf(w), F.eye.x), F.eye.y, fmaf(pc->rho, sinf(w), F.eye.z)}; /* :46 */
+    temp = sub3(ctr, p);                                                       /* :47 */
+    il   = 1.0f / sqrtf(fmaf(temp.y, temp.y, temp.x * temp.x));                /* :48 */
+    dirx = temp.x * il;
+    F.theta = acosf(dirx) * TRT_RAD2DEG;                                       /* :49 */
+    if(temp.y < 0.0f)                                                          /* :50 */
+      F.theta = 360.0f - F.theta;
+  }
+  return F;
+}
+
+static void raygen(const trt_globals* g, const trt_push* pc, const toro_frame* F, uint32_t W,
+                   uint32_t H, int camera, uint32_t x, uint32_t y, v3* origin, v3* dir)
+{
+  if(camera == TRT_CAMERA_TOROIDAL)
+  {
+    const float d_alfa = 360.0f / (float)W;                                    /* BEF rgen:25 */
+    const float d_beta = 360.0f / (float)H;                                    /* :26 */
+    const float alfa   = d_alfa * (float)x;                                    /* :27 */
+    const float beta   = d_beta * (float)y;                                    /* :28 */
+    const float aw     = (alfa + F->omega) * TRT_DEG2RAD;
+    const float bt     = (beta + F->theta) * TRT_DEG2RAD;
+    const float ca = cosf(aw), sa = sinf(aw), cb = cosf(bt), sb = sinf(bt);
+    origin->x = fmaf(pc->rho, ca, F->eye.x);                                   /* :56 */
+    origin->y = F->eye.y;
+    origin->z = fmaf(pc->rho, sa, F->eye.z);
+    dir->x = ca * cb;                                                          /* :57 */
+    dir->y = sb;
+    dir->z = sa * cb;
+    return;
+  }
+  /* pinhole: REFL/shaders/raytrace.rgen:42-48 */
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;                      /* :42 */
+  const float u = px / (float)W, v = py / (float)H;                            /* :43 */
+  const float dx = u * 2.0f - 1.0f, dy = v * 2.0f - 1.0f;                      /* :44 */
+  *origin        = mat4_mul(g->viewInverse, 0.0f, 0.0f, 0.0f, 1.0f);          /* :46 */
+  const v3 tgt   = mat4_mul(g->projInverse, dx, dy, 1.0f, 1.0f);              /* :47 */
+  const v3 tn    = normalize3(tgt);
+  *dir           = mat4_mul(g->viewInverse, tn.x, tn.y, tn.z, 0.0f);          /* :48 */
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* one pixel: raygen bounce loop + closest-hit shader + miss shaders                     */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  v3    color;               /* accumulated hitValue (rgen:61,76)                        */
+  float t0; v3 P0, N0; int id0; /* depth-0 hit record; miss: t=inf, P=N=0, id=-1           */
+  v3    rayO, rayD;          /* primary ray (BEF rgen:72-73)                             */
+} pixel_out;
+
+static void shade_pixel(const scene_t* S, const trt_globals* g, const trt_push* pc,
+                        const toro_frame* F, uint32_t W, uint32_t H, int camera, uint32_t x,
+                        uint32_t y, pixel_out* out, trt_stats* st)
+{
+  v3 origin, direction;
+  raygen(g, pc, F, W, H, camera, x, y, &origin, &direction);
+  out->rayO = origin;
+  out->rayD = direction;
+
+  const float tMin = 0.001f, tMax = 10000.0f;                                  /* rgen:51-52 */
+  int depth = 0, done = 1;                                                     /* rgen:54,57 */
+  v3  attenuation = {1.0f, 1.0f, 1.0f};                                        /* rgen:56 */
+  v3  hitValue    = {0.0f, 0.0f, 0.0f};                                        /* rgen:61 */
+  const v3 zero   = {0.0f, 0.0f, 0.0f};
+  const v3 lp     = {pc->lightPosition[0], pc->lightPosition[1], pc->lightPosition[2]};
+  out->t0 = INFINITY; out->P0 = zero; out->N0 = zero; out->id0 = -1;
+
+  for(;;)                                                                      /* rgen:62 */
+  {
+    v3       prdHit;
+    v3       nextO = origin, nextD = direction;
+    float    t;
+    uint64_t* ctr = depth == 0 ? &st->primary_tests : &st->bounce_tests;
+    const int id  = closest_hit(S, origin, direction, tMin, tMax, &t, ctr);    /* rgen:64-75 */
+    if(id < 0)
+    {
+      /* miss shader: REFL/shaders/raytrace.rmiss:37 (BEF rmiss:19-21: hitPosition = 0) */
+      prdHit.x = pc->clearColor[0] * 0.8f;
+      prdHit.y = pc->clearColor[1] * 0.8f;
+      prdHit.z = pc->clearColor[2] * 0.8f;
+    }
+    else
+    {
+      /* closest-hit shader: REFL/shaders/raytrace.rchit:50-156 */
+      const trt_material* mat = &S->mat[S->tori[id].matId];                    /* rchit:95-96 */
+      /* hit point O + D·t (BEF rchit:134; shadow origin rchit:116) */
+      const v3 P = {fmaf(t, direction.x, origin.x), fmaf(t, direction.y, origin.y),
+                    fmaf(t, direction.z, origin.z)};
+      const v3 N = torus_normal(S, id, P);
+      if(depth == 0) { out->t0 = t; out->P0 = P; out->N0 = N; out->id0 = id; } /* BEF rgen:94-97 */
+
+      v3    L;
+      float lightIntensity = pc->lightIntensity;                               /* rchit:79 */
+      float lightDistance  = 100000.0f;                                        /* rchit:80 */
+      if(pc->lightType == 0)                                                   /* rchit:82 */
+      {
+        const v3    lDir = sub3(lp, P);                                        /* rchit:84 */
+        const float l2   = dot3(lDir, lDir);
+        lightDistance    = sqrtf(l2);                                          /* rchit:85 */
+        lightIntensity   = pc->lightIntensity / (lightDistance * lightDistance); /* rchit:86 */
+        L                = scale3(lDir, 1.0f / lightDistance);                 /* rchit:87 */
+      }
+      else
+        L = normalize3(lp);                                                    /* rchit:91 */
+
+      const v3 diffuse     = compute_diffuse(mat, L, N);                       /* rchit:100 */
+      v3       specular    = zero;                                             /* rchit:108 */
+      float    attenuation1 = 1.0f;                                            /* rchit:109 */
+      if(dot3(N, L) > 0.0f)                                                    /* rchit:112 */
+      {
+        /* shadow ray: origin O + D·t, tMin .001, tMax lightDistance (rchit:114-131) */
+        if(any_hit(S, P, L, 0.001f, lightDistance, &st->shadow_tests))
+          attenuation1 = 0.3f;                                                 /* rchit:135 */
+        else
+          specular = compute_specular(mat, direction, L, N);                   /* rchit:140 */
+      }
+      if(mat->illum == 3)                                                      /* rchit:145 */
+      {
+        attenuation.x *= mat->specular[0];                                     /* rchit:149 */
+        attenuation.y *= mat->specular[1];
+        attenuation.z *= mat->specular[2];
+        done  = 0;                                                             /* rchit:150 */
+        nextO = P;                                                             /* rchit:151 */
+        nextD = reflect3(direction, N);                                        /* rchit:148,152 */
+      }
+      const float k = attenuation1 * lightIntensity;                           /* rchit:155 */
+      prdHit.x = k * (diffuse.x + specular.x);
+      prdHit.y = k * (diffuse.y + specular.y);
+      prdHit.z = k * (diffuse.z + specular.z);
+    }
+    hitValue.x = fmaf(prdHit.x, attenuation.x, hitValue.x);                    /* rgen:76 */
+    hitValue.y = fmaf(prdHit.y, attenuation.y, hitValue.y);
+    hitValue.z = fmaf(prdHit.z, attenuation.z, hitValue.z);
+
+    depth++;                                                                   /* rgen:78 */
+    if(done == 1 || depth >= pc->maxDepth)                                     /* rgen:79 */
+      break;
+    origin    = nextO;                                                         /* rgen:82 */
+    direction = nextD;                                                         /* rgen:83 */
+    done      = 1;                                                             /* rgen:84 */
+  }
+  out->color = hitValue;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* exported C entry points (loaded with ctypes by oracle/oracle.py)                      */
+/* ------------------------------------------------------------------------------------ */
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* Same contract as trt_render_dev (include/trt.h) on host buffers. */
+int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* scene, uint32_t W,
+                  uint32_t H, uint32_t row_begin, uint32_t row_end, int camera, int precision,
+                  int nthreads, float* rgba, trt_hits* hits, trt_rendered_data* rendered,
+                  trt_stats* stats)
+{
+  scene_t S;
+  int     rc = scene_prepare(scene, precision, &S);
+  if(rc) return rc;
+  if(!g || !pc || !W || !H || row_end > H || row_begin > row_end) return TRT_E_INVALID;
+  const toro_frame F = toroidal_frame(g, pc);
+  uint64_t np = 0, nb = 0, ns = 0;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1) \
+    reduction(+ : np, nb, ns)
+#endif
+  for(uint32_t y = row_begin; y < row_end; ++y)
+  {
+    trt_stats st = {0, 0, 0, 0};
+    for(uint32_t x = 0; x < W; ++x)
+    {
+      pixel_out o;
+      shade_pixel(&S, g, pc, &F, W, H, camera, x, y, &o, &st);
+      const size_t i = (size_t)y * W + x;
+      if(rgba)
+      {
+        rgba[4 * i + 0] = o.color.x;                                           /* rgen:87 */
+        rgba[4 * i + 1] = o.color.y;
+        rgba[4 * i + 2] = o.color.z;
+        rgba[4 * i + 3] = 1.0f;
+      }
+      if(hits)
+      {
+        if(hits->t) hits->t[i] = o.t0;
+        if(hits->px) hits->px[i] = o.P0.x;
+        if(hits->py) hits->py[i] = o.P0.y;
+        if(hits->pz) hits->pz[i] = o.P0.z;
+        if(hits->nx) hits->nx[i] = o.N0.x;
+        if(hits->ny) hits->ny[i] = o.N0.y;
+        if(hits->nz) hits->nz[i] = o.N0.z;
+        if(hits->id) hits->id[i] = o.id0;
+      }
+      if(rendered)
+      {
+        trt_rendered_data* r = &rendered[(size_t)x * H + y];                   /* BEF rgen:72 */
+        r->pos[0] = o.P0.x; r->pos[1] = o.P0.y; r->pos[2] = o.P0.z; r->pos[3] = 1.0f;   /* :112 */
+        r->color[0] = o.color.x; r->color[1] = o.color.y; r->color[2] = o.color.z;
+        r->color[3] = 1.0f;                                                    /* :111 */
+        r->rayOrigin[0] = o.rayO.x; r->rayOrigin[1] = o.rayO.y; r->rayOrigin[2] = o.rayO.z;
+        r->rayOrigin[3] = 1.0f;                                                /* :56,72 */
+        r->rayDir[0] = o.rayD.x; r->rayDir[1] = o.rayD.y; r->rayDir[2] = o.rayD.z;
+        r->rayDir[3] = 0.0f;                                                   /* :57,73 */
+      }
+    }
+    np += st.primary_tests;
+    nb += st.bounce_tests;
+    ns += st.shadow_tests;
+  }
+  if(stats)
+  {
+    stats->primary_tests = np;
+    stats->bounce_tests  = nb;
+    stats->shadow_tests  = ns;
+    stats->pixels        = (uint64_t)(row_end - row_begin) * W;
+  }
+  return TRT_OK;
+}
+
+/* Same contract as trt_trace (include/trt.h). */
+int oracle_trace(const trt_rays* in, const trt_scene* scene, float tmin, float tmax,
+                 int precision, int nthreads, trt_hits* out, trt_stats* stats)
+{
+  scene_t S;
+  int     rc = scene_prepare(scene, precision, &S);
+  if(rc) return rc;
+  if(!in || !out) return TRT_E_INVALID;
+  uint64_t np = 0;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : np)
+#endif
+  for(int64_t i = 0; i < (int64_t)in->n; ++i)
+  {
+    const v3 o = {in->ox[i], in->oy[i], in->oz[i]}, d = {in->dx[i], in->dy[i], in->dz[i]};
+    float    t;
+    uint64_t tests = 0;
+    const int id = closest_hit(&S, o, d, tmin, tmax, &t, &tests);
+    np += tests;
+    v3 P = {0.0f, 0.0f, 0.0f}, N = {0.0f, 0.0f, 0.0f};
+    if(id >= 0)
+    {
+      P.x = fmaf(t, d.x, o.x); P.y = fmaf(t, d.y, o.y); P.z = fmaf(t, d.z, o.z);
+      N   = torus_normal(&S, id, P);
+    }
+    if(out->t) out->t[i] = t;
+    if(out->px) out->px[i] = P.x;
+    if(out->py) out->py[i] = P.y;
+    if(out->pz) out->pz[i] = P.z;
+    if(out->nx) out->nx[i] = N.x;
+    if(out->ny) out->ny[i] = N.y;
+    if(out->nz) out->nz[i] = N.z;
+    if(out->id) out->id[i] = id;
+  }
+  if(stats)
+  {
+    stats->primary_tests = np;
+    stats->bounce_tests = stats->shadow_tests = 0;
+    stats->pixels = in->n;
+  }
+  return TRT_OK;
+}
+
+/* Primary ray of pixel (x,y): o[3], d[3]. */
+int oracle_raygen(const trt_globals* g, const trt_push* pc, uint32_t W, uint32_t H, int camera,
+                  uint32_t x, uint32_t y, float* o, float* d)
+{
+  if(!g || !pc || !o || !d) return TRT_E_INVALID;
+  const toro_frame F = toroidal_frame(g, pc);
+  v3 oo, dd;
+  raygen(g, pc, &F, W, H, camera, x, y, &oo, &dd);
+  o[0] = oo.x; o[1] = oo.y; o[2] = oo.z;
+  d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+  return TRT_OK;
+}
+
+/* omega, theta (degrees) and eye of the toroidal camera frame. */
+int oracle_toroidal_frame(const trt_globals* g, const trt_push* pc, float* omega_theta_eye)
+{
+  if(!g || !pc || !omega_theta_eye) return TRT_E_INVALID;
+  const toro_frame F = toroidal_frame(g, pc);
+  omega_theta_eye[0] = F.omega; omega_theta_eye[1] = F.theta;
+  omega_theta_eye[2] = F.eye.x; omega_theta_eye[3] = F.eye.y; omega_theta_eye[4] = F.eye.z;
+  return TRT_OK;
+}
+
+/* GLSL reflect(), exposed for the known-answer test k7. */
+void oracle_reflect(const float* i, const float* n, float* r)
+{
+  const v3 I = {i[0], i[1], i[2]}, N = {n[0], n[1], n[2]};
+  const v3 R = reflect3(I, N);
+  r[0] = R.x; r[1] = R.y; r[2] = R.z;
+}
+
+/* Single ray vs single torus with evaluation count, both precisions (diagnostics). */
+int oracle_torus_first_hit(const trt_torus* T, const float* o, const float* d, float tmin,
+                           float tmax, int precision, double* t_out, int* evals)
+{
+  int ne = 0, hit;
+  if(precision == TRT_SOLVE_F64)
+  {
+    torus_k_f64 k;
+    torus_prepare_f64(T, &k);
+    const double o64[3] = {o[0], o[1], o[2]}, d64[3] = {d[0], d[1], d[2]};
+    const double dd = fma(d64[2], d64[2], fma(d64[1], d64[1], d64[0] * d64[0]));
+    double t;
+    hit = torus_first_hit_f64(o64, d64, dd, 1.0 / dd, tmin, tmax, &k, &t, &ne);
+    if(hit) *t_out = t;
+  }
+  else
+  {
+    torus_k_f32 k;
+    torus_prepare_f32(T, &k);
+    const float dd = fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0]));
+    float t;
+    hit = torus_first_hit_f32(o, d, dd, 1.0f / dd, tmin, tmax, &k, &t, &ne);
+    if(hit) *t_out = (double)t;
+  }
+  if(evals) *evals = ne;
+  return hit;
+}
