@@ -1,0 +1,306 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and — at BASELINE sizes — through
+size-independent properties.
+
+Bars (BASELINE.json north_star): hit/miss classification and torus id BIT-EXACT; here the
+geometric outputs (t, P, N) are also required bit-exact because both sides execute the
+same correctly-rounded operation DAG; colours within 1e-5 relative (+1e-6 absolute) because
+pow()/cos()/sin() come from different maths libraries (OCML vs glibc)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, seeded_rays
+from toroidal_ray_tracing_amd import abi, camera
+
+pytestmark = pytest.mark.gpu
+
+GEOM = ("t", "px", "py", "pz", "nx", "ny", "nz")
+COLOR_RTOL, COLOR_ATOL = 1e-5, 1e-6
+
+
+@pytest.fixture(scope="module")
+def tr():
+    from toroidal_ray_tracing_amd.tracer import Tracer
+    t = Tracer(0)
+    yield t
+    t.close()
+
+
+def assert_hits_equal(a, b, what=""):
+    np.testing.assert_array_equal(a["id"], b["id"], err_msg=what + " id")
+    for k in GEOM:
+        np.testing.assert_array_equal(a[k].view(np.uint32), b[k].view(np.uint32), err_msg=f"{what} {k} bits")
+
+
+SCENES = {
+    "single": lambda: camera.single_torus_scene(),
+    "thin_offset": lambda: camera.single_torus_scene(center=(0.3, -0.2, 0.5), R=2.0, r=0.1),
+    "fat": lambda: camera.single_torus_scene(R=1.0, r=0.9),
+    "nested8": lambda: camera.nested_tori_scene(),
+}
+
+
+@pytest.mark.parametrize("scene", list(SCENES))
+@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64], ids=["f32", "f64"])
+def test_trace_bit_exact_vs_oracle(tr, oracle, scene, precision):
+    sc = SCENES[scene]()
+    o, d = seeded_rays(100_003, 1234, center=sc.tori_list()[0][0], box=5.0, reach=2.4)
+    tr.set_solver(precision)
+    try:
+        got = tr.trace(sc, o, d)
+    finally:
+        tr.set_solver(abi.TRT_SOLVE_F32)
+    want, _ = oracle.trace(sc, o, d, precision=precision, nthreads=8)
+    assert np.isfinite(want["t"]).mean() > 0.05
+    assert_hits_equal(got, want, scene)
+
+
+@pytest.mark.parametrize("name", ["rays_single", "rays_thin_offset", "rays_nested"])
+def test_trace_vs_golden_fp64_truth(tr, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    tori = [((c[0], c[1], c[2]), c[3], c[4]) for c in z["tori"]]
+    sc = abi.Scene([(c, R, r, 0) for c, R, r in tori], [camera.MIRROR])
+    got = tr.trace(sc, z["o"], z["d"])
+    hit_g, hit_t, rob = np.isfinite(got["t"]), np.isfinite(z["t"]), z["robust"]
+    assert not np.any((hit_g != hit_t) & rob)
+    both = hit_g & hit_t & rob
+    np.testing.assert_array_equal(got["id"][both], z["id"][both])
+    assert (np.abs(got["t"][both] - z["t"][both]) / np.maximum(1, z["t"][both])).max() < 1e-5
+
+
+def test_trace_edge_cases(tr, oracle):
+    sc = camera.single_torus_scene()
+    # empty input
+    assert all(len(v) == 0 for v in tr.trace(sc, np.zeros((0, 3)), np.zeros((0, 3))).values())
+    # ragged sizes around the wavefront / block size
+    for n in (1, 63, 64, 65, 255, 257, 1000):
+        o, d = seeded_rays(n, n)
+        assert_hits_equal(tr.trace(sc, o, d), oracle.trace(sc, o, d)[0], f"n={n}")
+    # degenerate rays: zero direction, NaN, inf, huge origin, non-unit direction, origin on surface
+    o = np.float32([[0, 0, 0], [np.nan, 0, 0], [-5, 0, 0], [1e6, 0, 0], [-5, 0.1, 0.05], [-1.25, 0, 0],
+                    [-5, 0, 0], [0, 5, 0], [1, 5, 0]])
+    d = np.float32([[0, 0, 0], [1, 0, 0], [np.inf, 0, 0], [-1, 0, 0], [2.5, 0, 0], [1, 0, 0],
+                    [1, 0, 0], [0, -1, 0], [0, -1, 0]])
+    got, want = tr.trace(sc, o, d), oracle.trace(sc, o, d)[0]
+    assert_hits_equal(got, want, "degenerate")
+    assert got["id"][0] == -1 and got["id"][1] == -1 and np.isposinf(got["t"][0])
+    assert got["t"][6] == 3.75 and got["id"][7] == -1 and got["t"][8] == 4.75
+    # tmin/tmax window
+    o, d = seeded_rays(5000, 5)
+    assert_hits_equal(tr.trace(sc, o, d, 2.0, 4.0), oracle.trace(sc, o, d, 2.0, 4.0)[0], "window")
+
+
+def test_trace_null_streams(tr):
+    """Any output stream may be NULL (include/trt.h)."""
+    import ctypes as C
+    sc = camera.single_torus_scene()
+    o, d = seeded_rays(1000, 9)
+    oo, dd = np.ascontiguousarray(o.T), np.ascontiguousarray(d.T)
+    rays = abi.rays_struct([oo[0], oo[1], oo[2], dd[0], dd[1], dd[2]], 1000)
+    t = np.empty(1000, np.float32)
+    hs = abi.hits_struct({"t": t})
+    assert tr._L.trt_trace(tr._h, C.byref(rays), C.byref(sc.c), 0.001, 1e4, C.byref(hs)) == 0
+    np.testing.assert_array_equal(t, tr.trace(sc, o, d)["t"])
+
+
+def test_error_codes(tr):
+    from toroidal_ray_tracing_amd.tracer import TrtError
+    o, d = seeded_rays(10, 1)
+    for bad in (abi.Scene([((0, 0, 0), 1.0, 1.5, 0)], [camera.MIRROR]),
+                abi.Scene([((0, 0, 0), 1.0, 0.2, 2)], [camera.MIRROR])):
+        with pytest.raises(TrtError) as e:
+            tr.trace(bad, o, d)
+        assert e.value.code == abi.TRT_E_SCENE
+    with pytest.raises(TrtError) as e:
+        tr.render(camera.single_torus_scene(), camera.baseline_camera(8, 8), camera.baseline_push(1), 0, 8)
+    assert e.value.code == abi.TRT_E_INVALID
+    with pytest.raises(TrtError):
+        tr.set_render_variant("nope")
+
+
+RENDERS = {
+    "mirror_d1": lambda W, H: (camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(1), 0),
+    "mirror_d5": lambda W, H: (camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(5), 0),
+    "mirror_d10": lambda W, H: (camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(10), 0),
+    "plastic_dir": lambda W, H: (camera.single_torus_scene(material=camera.PLASTIC), camera.baseline_camera(W, H),
+                                 abi.make_push(max_depth=3, light_type=1), 0),
+    "matte": lambda W, H: (camera.single_torus_scene(material=camera.MATTE), camera.baseline_camera(W, H),
+                           camera.baseline_push(4), 0),
+    "flat_lowlight": lambda W, H: (camera.single_torus_scene(material=camera.FLAT), camera.baseline_camera(W, H),
+                                   abi.make_push(max_depth=2, light_pos=(0, -50, 0)), 0),
+    "nested_d5": lambda W, H: (camera.nested_tori_scene(), camera.baseline_camera(W, H), camera.baseline_push(5), 0),
+    "toroidal_interior": lambda W, H: (
+        camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC), camera.toroidal_camera(W, H),
+        abi.make_push(max_depth=5, rho=4.0), 1),
+    "toroidal_survey": lambda W, H: (   # SURVEY §8d secondary run: torus moved to (10,0,0)
+        camera.single_torus_scene(center=(10.0, 0.0, 0.0), R=3.0, r=1.0), camera.toroidal_camera(W, H),
+        abi.make_push(max_depth=5, rho=4.0), 1),
+    "toroidal_tilted": lambda W, H: (   # eye.y != center.y exercises theta (BEF rgen:45-53)
+        camera.single_torus_scene(R=6.0, r=1.5, material=camera.MIRROR),
+        camera.toroidal_camera(W, H, eye=(0.5, 0.4, -0.3), center=(4.0, -1.0, 7.0)),
+        abi.make_push(max_depth=4, rho=3.0), 1),
+}
+
+
+def check_render(tr, oracle, sc, g, pc, W, H, cam, precision=abi.TRT_SOLVE_F32):
+    rgba, hits = tr.render(sc, g, pc, W, H, cam)
+    wr, wh, _, wstats = oracle.render(sc, g, pc, W, H, cam, precision=precision, nthreads=8)
+    assert_hits_equal(hits, wh, "first-hit record")
+    np.testing.assert_allclose(rgba, wr, rtol=COLOR_RTOL, atol=COLOR_ATOL)
+    return rgba, hits, wstats
+
+
+@pytest.mark.parametrize("variant", ["static", "persistent"])
+@pytest.mark.parametrize("name", list(RENDERS))
+def test_render_parity(tr, oracle, name, variant):
+    W, H = 200, 136   # not multiples of the 8x8 tile
+    sc, g, pc, cam = RENDERS[name](W, H)
+    tr.set_render_variant(variant)
+    tr.enable_stats(True)
+    try:
+        _, hits, wstats = check_render(tr, oracle, sc, g, pc, W, H, cam)
+        st = tr.stats()
+    finally:
+        tr.enable_stats(False)
+        tr.set_render_variant("static")
+    # the same queries were executed: bounce/shadow decisions are bit-exact too
+    assert st == {**wstats}
+
+
+@pytest.mark.parametrize("variant", ["static", "persistent"])
+def test_render_fp64_nested(tr, oracle, variant):
+    W, H = 160, 120
+    sc, g, pc = camera.nested_tori_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
+    tr.set_solver(abi.TRT_SOLVE_F64)
+    tr.set_render_variant(variant)
+    try:
+        check_render(tr, oracle, sc, g, pc, W, H, 0, abi.TRT_SOLVE_F64)
+    finally:
+        tr.set_solver(abi.TRT_SOLVE_F32)
+        tr.set_render_variant("static")
+
+
+@pytest.mark.parametrize("name,cam", [("render_pinhole_mirror", 0), ("render_toroidal_plastic", 1)])
+def test_render_vs_golden(tr, name, cam):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    W = H = 64
+    pc = camera.baseline_push(5)
+    if cam == 0:
+        sc, g = camera.single_torus_scene(), camera.baseline_camera(W, H)
+    else:
+        sc = camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC)
+        g = camera.toroidal_camera(W, H)
+        pc.rho = 4.0
+    rgba, hits = tr.render(sc, g, pc, W, H, cam)
+    np.testing.assert_allclose(rgba, z["rgba"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(np.isfinite(hits["t"]), np.isfinite(z["hit_t"]))
+    np.testing.assert_array_equal(hits["id"], z["hit_id"])
+    m = np.isfinite(z["hit_t"])
+    np.testing.assert_allclose(hits["t"][m], z["hit_t"][m], rtol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ["static", "persistent"])
+def test_render_dev_rows_and_rendered_data(tr, oracle, variant):
+    """Device-pointer entry point: row bands tile the frame; RenderedData AoS at x*H+y."""
+    import torch
+    W, H = 96, 72
+    sc, g, pc = camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC), camera.toroidal_camera(W, H), \
+        abi.make_push(max_depth=3, rho=4.0)
+    dev = torch.device("cuda:0")
+    rgba = torch.zeros(H, W, 4, device=dev)
+    rend = torch.zeros(W * H, 16, device=dev)
+    hit_t = torch.full((H * W,), -1.0, device=dev)
+    tr.set_render_variant(variant)
+    try:
+        s = torch.cuda.current_stream().cuda_stream
+        for rows in ((0, 17), (17, 50), (50, 72)):
+            tr.render_dev(sc, g, pc, W, H, rgba.data_ptr(), rows=rows, camera=1,
+                          hit_ptrs={"t": hit_t.data_ptr()}, rendered_ptr=rend.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+    finally:
+        tr.set_render_variant("static")
+    wr, wh, wrend, _ = oracle.render(sc, g, pc, W, H, 1, want_rendered=True, nthreads=8)
+    np.testing.assert_allclose(rgba.cpu().numpy(), wr, rtol=COLOR_RTOL, atol=COLOR_ATOL)
+    np.testing.assert_array_equal(hit_t.cpu().numpy().view(np.uint32), wh["t"].view(np.uint32))
+    got = rend.cpu().numpy()
+    np.testing.assert_array_equal(got[:, [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15]].view(np.uint32),
+                                  wrend[:, [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15]].view(np.uint32))
+    np.testing.assert_allclose(got[:, 4:8], wrend[:, 4:8], rtol=COLOR_RTOL, atol=COLOR_ATOL)
+    # a band leaves the other rows untouched
+    rgba.zero_()
+    tr.render_dev(sc, g, pc, W, H, rgba.data_ptr(), rows=(10, 20), camera=1, stream=s)
+    torch.cuda.synchronize()
+    out = rgba.cpu().numpy()
+    assert np.all(out[:10] == 0) and np.all(out[20:] == 0) and np.all(out[10:20, :, 3] == 1)
+
+
+@pytest.mark.parametrize("variant", ["static", "persistent"])
+def test_full_size_properties(tr, variant):
+    """BASELINE config 3 (4096², maxDepth 5 = 4 bounces): properties that need no oracle.
+    Left-right mirror symmetry of the scene is NOT used (the light breaks it); instead:
+    every recorded hit point lies on the torus, normals are unit and point against the ray,
+    t matches |P - eye|, misses carry the clear colour, and the static and persistent
+    kernels agree bit for bit on the geometric record."""
+    import torch
+    W = H = 4096
+    sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
+    dev = torch.device("cuda:0")
+    rgba = torch.empty(H, W, 4, device=dev)
+    hb = {k: torch.empty(H * W, device=dev) for k in GEOM}
+    hid = torch.empty(H * W, dtype=torch.int32, device=dev)
+    tr.set_render_variant(variant)
+    try:
+        tr.render_dev(sc, g, pc, W, H, rgba.data_ptr(),
+                      hit_ptrs={**{k: v.data_ptr() for k, v in hb.items()}, "id": hid.data_ptr()},
+                      stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        tr.set_render_variant("static")
+    hit = hid >= 0
+    assert 0.05 < hit.float().mean().item() < 0.5
+    P = torch.stack([hb["px"], hb["py"], hb["pz"]], 1)[hit].double()
+    N = torch.stack([hb["nx"], hb["ny"], hb["nz"]], 1)[hit].double()
+    rho = torch.hypot(P[:, 0], P[:, 2])
+    gval = (rho - 1.0) ** 2 + P[:, 1] ** 2 - 0.25 ** 2
+    assert gval.abs().max().item() < 5e-6            # on the surface (|g| ~ 2 r dist)
+    assert (N.norm(dim=1) - 1).abs().max().item() < 3e-7
+    eye = torch.tensor([0.0, 1.5, -4.0], dtype=torch.float64, device=dev)
+    D = P - eye
+    assert ((D * N).sum(1) <= 1e-6).all()            # first hit faces the camera
+    assert (D.norm(dim=1) - hb["t"][hit].double()).abs().max().item() < 2e-5
+    miss = ~hit
+    assert torch.isinf(hb["t"][miss]).all() and (hb["px"][miss] == 0).all()
+    img = rgba.view(-1, 4)
+    assert (img[miss][:, :3] == 0.8).all() and (img[:, 3] == 1).all()
+    assert torch.isfinite(img).all() and (img[:, :3] >= 0).all()
+    # checksum pinned across kernel variants (bit-exact geometry)
+    csum = {k: int(v.view(torch.int32).long().sum().item()) for k, v in hb.items()}
+    prev = test_full_size_properties.__dict__.setdefault("csum", csum)
+    assert prev == csum
+
+
+def test_trace_dev_full_size_matches_render(tr):
+    """BASELINE config 2 shape (2048² primary rays, 0 bounces) through trace_dev: feeding the
+    primary rays exported by the render (RenderedData.rayOrigin/rayDir) back into trace()
+    reproduces the render's first-hit record bit for bit."""
+    import torch
+    W = H = 2048
+    sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(1)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    rend = torch.empty(W * H, 16, device=dev)
+    t_r = torch.empty(H * W, device=dev)
+    nx_r = torch.empty(H * W, device=dev)
+    tr.render_dev(sc, g, pc, W, H, 0, hit_ptrs={"t": t_r.data_ptr(), "nx": nx_r.data_ptr()},
+                  rendered_ptr=rend.data_ptr(), stream=s)
+    r = rend.view(W, H, 16).permute(1, 0, 2).reshape(-1, 16)   # x*H+y -> y*W+x
+    rays = [r[:, 8 + k].contiguous() for k in range(3)] + [r[:, 12 + k].contiguous() for k in range(3)]
+    t_t = torch.empty(H * W, device=dev)
+    nx_t = torch.empty(H * W, device=dev)
+    tr.trace_dev(sc, [a.data_ptr() for a in rays], W * H, {"t": t_t.data_ptr(), "nx": nx_t.data_ptr()}, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(t_r.view(torch.int32), t_t.view(torch.int32))
+    assert torch.equal(nx_r.view(torch.int32), nx_t.view(torch.int32))
+    assert 0.05 < torch.isfinite(t_t).float().mean().item() < 0.5

@@ -1,0 +1,479 @@
+// trt_api.hip — implementation of the C ABI declared in include/trt.h.
+//
+// Host side of the drop-in boundary: validates arguments, derives the per-torus solver
+// constants and the toroidal camera frame, owns grow-only device staging buffers for the
+// host-pointer entry points, and launches the gfx950 kernels.  Replaces what
+// HelloVulkan::raytrace + the descriptor-set / push-constant plumbing do in the reference
+// (REFL/hello_vulkan.cpp:913-935, BEF/hello_vulkan.cpp:936-958).  Nothing in here computes
+// a ray on the CPU: without a HIP device trt_create fails.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "trt_kernels.hpp"
+
+using namespace trt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void*  p   = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct trt_ctx {
+  int           device    = 0;
+  int           n_cus     = 256;
+  int           precision = TRT_SOLVE_F32;
+  RenderVariant variant   = kRenderStatic;
+  bool          stats_on  = false;
+  std::string   err;
+  hipStream_t   last_stream = nullptr;
+
+  unsigned long long* d_stats = nullptr;  // [4]
+  unsigned int*       d_queue = nullptr;  // persistent kernel work counter
+  uint64_t            stats_pixels = 0;
+
+  // toroidal camera tables: device copy + pinned host staging + cache key
+  DevBuf d_toro;
+  float* h_toro     = nullptr;
+  size_t h_toro_cap = 0;
+  struct { uint32_t W = 0, H = 0; float omega = 0, theta = 0; bool valid = false; } toro_key;
+
+  // staging for the host-pointer entry points (grow-only, freed in trt_destroy)
+  DevBuf d_in[6], d_out[8], d_rgba, d_rendered;
+};
+
+namespace {
+
+int fail(trt_ctx* ctx, int code, const char* fmt, ...)
+{
+  char    buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if(ctx) ctx->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define TRT_HIP(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if(e_ != hipSuccess)                                                                    \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? TRT_E_NOMEM : TRT_E_HIP, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                   \
+  } while(0)
+
+int grow(trt_ctx* ctx, DevBuf& b, size_t bytes)
+{
+  if(bytes <= b.cap) return TRT_OK;
+  if(b.p) TRT_HIP(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  TRT_HIP(ctx, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return TRT_OK;
+}
+
+template <class Real>
+void torus_prepare(const trt_torus& t, TorusK<Real>& k)
+{
+  const Real R = (Real)t.R, r = (Real)t.r;
+  const Real R2 = R * R, r2 = r * r, s = R + r, s2 = s * s;
+  k.cx = (Real)t.center[0];
+  k.cy = (Real)t.center[1];
+  k.cz = (Real)t.center[2];
+  k.R      = R;
+  k.r2     = r2;
+  k.rpol   = r * (Real)0.03125;
+  k.k0     = R2 - r2;
+  k.Rb2    = std::fma(s2, (Real)0.001953125, s2);
+  k.fourR2 = (Real)4 * R2;
+}
+
+int build_scene(trt_ctx* ctx, const trt_scene* s, SceneK& out)
+{
+  if(!s || !s->tori || !s->materials)
+    return fail(ctx, TRT_E_INVALID, "scene: NULL scene / tori / materials");
+  if(s->n_tori < 1 || s->n_tori > TRT_MAX_TORI)
+    return fail(ctx, TRT_E_SCENE, "scene: n_tori=%u outside 1..%d", s->n_tori, TRT_MAX_TORI);
+  if(s->n_materials < 1 || s->n_materials > TRT_MAX_MATERIALS)
+    return fail(ctx, TRT_E_SCENE, "scene: n_materials=%u outside 1..%d", s->n_materials,
+                TRT_MAX_MATERIALS);
+  std::memset(&out, 0, sizeof out);
+  out.n_tori = (int)s->n_tori;
+  out.n_mat  = (int)s->n_materials;
+  out.f64    = ctx->precision == TRT_SOLVE_F64;
+  for(uint32_t i = 0; i < s->n_tori; ++i)
+  {
+    const trt_torus& t = s->tori[i];
+    if(!(t.r > 0.0f && t.R > t.r))
+      return fail(ctx, TRT_E_SCENE, "scene: torus %u is not a ring torus (R=%g, r=%g; need 0<r<R)", i,
+                  (double)t.R, (double)t.r);
+    if(t.matId < 0 || (uint32_t)t.matId >= s->n_materials)
+      return fail(ctx, TRT_E_SCENE, "scene: torus %u has matId=%d outside 0..%u", i, t.matId,
+                  s->n_materials - 1);
+    torus_prepare<float>(t, out.k32[i]);
+    torus_prepare<double>(t, out.k64[i]);
+    out.shade[i] = {t.center[0], t.center[1], t.center[2], t.R, t.matId};
+  }
+  for(uint32_t i = 0; i < s->n_materials; ++i)
+  {
+    const trt_material& m = s->materials[i];
+    if(m.textureId >= 0)
+      return fail(ctx, TRT_E_SCENE, "scene: material %u has textureId=%d; tori are untextured", i,
+                  m.textureId);
+    MaterialK& k = out.mat[i];
+    std::memcpy(k.ambient, m.ambient, sizeof k.ambient);
+    std::memcpy(k.diffuse, m.diffuse, sizeof k.diffuse);
+    std::memcpy(k.specular, m.specular, sizeof k.specular);
+    k.shininess = m.shininess;
+    k.illum     = m.illum;
+  }
+  return TRT_OK;
+}
+
+// column-major mat4 · (0,0,0,1), rows 0..2 — same accumulation order as the kernels
+void mat4_origin(const float* m, float out[3])
+{
+  for(int r = 0; r < 3; ++r)
+    out[r] = std::fma(m[12 + r], 1.0f, std::fma(m[8 + r], 0.0f, std::fma(m[4 + r], 0.0f, m[r] * 0.0f)));
+}
+
+constexpr float kDeg2Rad = 0.017453292519943295f;  // GLSL radians()
+constexpr float kRad2Deg = 57.29577951308232f;     // GLSL degrees()
+
+// Per-frame part of the toroidal camera (BEF/shaders/raytrace.rgen:36-53) and the
+// per-column / per-row trigonometry of :25-28,56-57, evaluated once on the host.
+int build_toro(trt_ctx* ctx, const trt_globals& g, const trt_push& pc, uint32_t W, uint32_t H,
+               hipStream_t stream, ToroCam& out)
+{
+  float eye[3];
+  mat4_origin(g.viewInverse, eye);                                           // :36
+  float tx = g.center[0] - eye[0], ty, tz = g.center[2] - eye[2];            // :38
+  float il    = 1.0f / std::sqrt(std::fma(tz, tz, tx * tx));                 // :39
+  float omega = std::acos(tx * il) * kRad2Deg;                               // :40
+  if(tz < 0.0f) omega = 360.0f - omega;                                      // :41-43
+  float theta = 0.0f;
+  if(eye[1] != g.center[1])                                                  // :45
+  {
+    const float w  = omega * kDeg2Rad;
+    const float p0 = std::fma(pc.rho, std::cos(w), eye[0]);                  // :46
+    tx = g.center[0] - p0;                                                   // :47
+    ty = g.center[1] - eye[1];
+    il = 1.0f / std::sqrt(std::fma(ty, ty, tx * tx));                        // :48
+    theta = std::acos(tx * il) * kRad2Deg;                                   // :49
+    if(ty < 0.0f) theta = 360.0f - theta;                                    // :50-52
+  }
+  const size_t n = 2 * ((size_t)W + H);
+  if(int rc = grow(ctx, ctx->d_toro, n * sizeof(float))) return rc;
+  auto& key = ctx->toro_key;
+  // bit-compare the angles so that a NaN frame (eye above centre) still caches
+  const bool same = key.valid && key.W == W && key.H == H && !std::memcmp(&key.omega, &omega, 4)
+                    && !std::memcmp(&key.theta, &theta, 4);
+  if(!same)
+  {
+    if(ctx->h_toro_cap < n)
+    {
+      if(ctx->h_toro) TRT_HIP(ctx, hipHostFree(ctx->h_toro));
+      ctx->h_toro = nullptr;
+      ctx->h_toro_cap = 0;
+      TRT_HIP(ctx, hipHostMalloc((void**)&ctx->h_toro, n * sizeof(float), hipHostMallocDefault));
+      ctx->h_toro_cap = n;
+    }
+    else if(ctx->last_stream || key.valid)
+      TRT_HIP(ctx, hipStreamSynchronize(ctx->last_stream));  // an earlier upload may be reading it
+    float* ca = ctx->h_toro, *sa = ca + W, *cb = sa + W, *sb = cb + H;
+    const float d_alfa = 360.0f / (float)W, d_beta = 360.0f / (float)H;      // :25-26
+    for(uint32_t x = 0; x < W; ++x)
+    {
+      const float aw = (d_alfa * (float)x + omega) * kDeg2Rad;               // :27,56
+      ca[x] = std::cos(aw);
+      sa[x] = std::sin(aw);
+    }
+    for(uint32_t y = 0; y < H; ++y)
+    {
+      const float bt = (d_beta * (float)y + theta) * kDeg2Rad;               // :28,57
+      cb[y] = std::cos(bt);
+      sb[y] = std::sin(bt);
+    }
+    TRT_HIP(ctx, hipMemcpyAsync(ctx->d_toro.p, ctx->h_toro, n * sizeof(float), hipMemcpyHostToDevice,
+                                stream));
+    key.W = W; key.H = H; key.omega = omega; key.theta = theta; key.valid = true;
+  }
+  out.eye[0] = eye[0]; out.eye[1] = eye[1]; out.eye[2] = eye[2];
+  out.rho   = pc.rho;
+  out.cos_a = (const float*)ctx->d_toro.p;
+  out.sin_a = out.cos_a + W;
+  out.cos_b = out.sin_a + W;
+  out.sin_b = out.cos_b + H;
+  return TRT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------------
+extern "C" int trt_version(void) { return TRT_VERSION_MAJOR * 1000 + TRT_VERSION_MINOR; }
+
+extern "C" const char* trt_last_error(const trt_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int trt_create(int device, trt_ctx** out)
+{
+  if(!out) return fail(nullptr, TRT_E_INVALID, "trt_create: out is NULL");
+  *out = nullptr;
+  int        n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if(e != hipSuccess || n <= 0)
+    return fail(nullptr, TRT_E_NO_DEVICE,
+                "trt_create: no HIP device (%s); this library has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if(device < 0 || device >= n)
+    return fail(nullptr, TRT_E_NO_DEVICE, "trt_create: device %d outside 0..%d", device, n - 1);
+  trt_ctx* ctx = new(std::nothrow) trt_ctx;
+  if(!ctx) return fail(nullptr, TRT_E_NOMEM, "trt_create: out of host memory");
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess
+     || (e = hipMalloc((void**)&ctx->d_stats, 4 * sizeof(unsigned long long))) != hipSuccess
+     || (e = hipMalloc((void**)&ctx->d_queue, 64 * sizeof(unsigned int))) != hipSuccess
+     || (e = hipMemset(ctx->d_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess)
+  {
+    fail(nullptr, TRT_E_HIP, "trt_create: %s", hipGetErrorString(e));
+    trt_destroy(ctx);
+    return TRT_E_HIP;
+  }
+  ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = ctx;
+  return TRT_OK;
+}
+
+extern "C" void trt_destroy(trt_ctx* ctx)
+{
+  if(!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if(ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if(ctx->d_queue) (void)hipFree(ctx->d_queue);
+  if(ctx->h_toro) (void)hipHostFree(ctx->h_toro);
+  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered};
+  for(DevBuf* b : all)
+    if(b->p) (void)hipFree(b->p);
+  for(DevBuf& b : ctx->d_in)
+    if(b.p) (void)hipFree(b.p);
+  for(DevBuf& b : ctx->d_out)
+    if(b.p) (void)hipFree(b.p);
+  delete ctx;
+}
+
+extern "C" int trt_set_solver(trt_ctx* ctx, int precision)
+{
+  if(!ctx) return TRT_E_INVALID;
+  if(precision != TRT_SOLVE_F32 && precision != TRT_SOLVE_F64)
+    return fail(ctx, TRT_E_INVALID, "trt_set_solver: precision %d is neither TRT_SOLVE_F32 nor _F64", precision);
+  ctx->precision = precision;
+  return TRT_OK;
+}
+
+extern "C" int trt_set_render_variant(trt_ctx* ctx, const char* name)
+{
+  if(!ctx || !name) return TRT_E_INVALID;
+  if(!std::strcmp(name, "static")) ctx->variant = kRenderStatic;
+  else if(!std::strcmp(name, "persistent")) ctx->variant = kRenderPersistent;
+  else return fail(ctx, TRT_E_INVALID, "trt_set_render_variant: unknown variant '%s'", name);
+  return TRT_OK;
+}
+
+extern "C" const char* trt_get_render_variant(const trt_ctx* ctx)
+{
+  if(!ctx) return "";
+  return ctx->variant == kRenderPersistent ? "persistent" : "static";
+}
+
+extern "C" int trt_enable_stats(trt_ctx* ctx, int on)
+{
+  if(!ctx) return TRT_E_INVALID;
+  ctx->stats_on = on != 0;
+  return TRT_OK;
+}
+
+extern "C" int trt_get_stats(trt_ctx* ctx, trt_stats* out)
+{
+  if(!ctx || !out) return TRT_E_INVALID;
+  TRT_HIP(ctx, hipSetDevice(ctx->device));
+  TRT_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+  unsigned long long h[4];
+  TRT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  out->primary_tests = h[0];
+  out->bounce_tests  = h[1];
+  out->shadow_tests  = h[2];
+  out->pixels        = ctx->stats_pixels;
+  return TRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// trace
+// ------------------------------------------------------------------------------------------
+extern "C" int trt_trace_dev(trt_ctx* ctx, const trt_rays* in, const trt_scene* scene, float tmin,
+                             float tmax, trt_hits* out, void* stream)
+{
+  if(!ctx) return TRT_E_INVALID;
+  if(!in || !out) return fail(ctx, TRT_E_INVALID, "trt_trace: NULL rays or hits");
+  if(in->n && (!in->ox || !in->oy || !in->oz || !in->dx || !in->dy || !in->dz))
+    return fail(ctx, TRT_E_INVALID, "trt_trace: NULL ray stream");
+  SceneK S;
+  if(int rc = build_scene(ctx, scene, S)) return rc;
+  TRT_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  TraceArgs   a;
+  a.rays  = *in;
+  a.hits  = *out;
+  a.tmin  = tmin;
+  a.tmax  = tmax;
+  a.stats = nullptr;
+  if(ctx->stats_on)
+  {
+    TRT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), st));
+    a.stats           = ctx->d_stats;
+    ctx->stats_pixels = in->n;
+  }
+  ctx->last_stream = st;
+  TRT_HIP(ctx, launch_trace(S, a, st));
+  return TRT_OK;
+}
+
+extern "C" int trt_trace(trt_ctx* ctx, const trt_rays* in, const trt_scene* scene, float tmin,
+                         float tmax, trt_hits* out)
+{
+  if(!ctx) return TRT_E_INVALID;
+  if(!in || !out) return fail(ctx, TRT_E_INVALID, "trt_trace: NULL rays or hits");
+  if(in->n && (!in->ox || !in->oy || !in->oz || !in->dx || !in->dy || !in->dz))
+    return fail(ctx, TRT_E_INVALID, "trt_trace: NULL ray stream");
+  TRT_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)in->n * sizeof(float);
+  const float* src[6] = {in->ox, in->oy, in->oz, in->dx, in->dy, in->dz};
+  void*        dst[8] = {out->t, out->px, out->py, out->pz, out->nx, out->ny, out->nz, out->id};
+  trt_rays din = *in;
+  trt_hits dout;
+  const float** dptr_in[6] = {&din.ox, &din.oy, &din.oz, &din.dx, &din.dy, &din.dz};
+  for(int k = 0; k < 6 && in->n; ++k)
+  {
+    if(int rc = grow(ctx, ctx->d_in[k], bytes)) return rc;
+    TRT_HIP(ctx, hipMemcpyAsync(ctx->d_in[k].p, src[k], bytes, hipMemcpyHostToDevice, nullptr));
+    *dptr_in[k] = (const float*)ctx->d_in[k].p;
+  }
+  void** dptr_out[8] = {(void**)&dout.t,  (void**)&dout.px, (void**)&dout.py, (void**)&dout.pz,
+                        (void**)&dout.nx, (void**)&dout.ny, (void**)&dout.nz, (void**)&dout.id};
+  for(int k = 0; k < 8; ++k)
+  {
+    *dptr_out[k] = nullptr;
+    if(dst[k] && in->n)
+    {
+      if(int rc = grow(ctx, ctx->d_out[k], bytes)) return rc;
+      *dptr_out[k] = ctx->d_out[k].p;
+    }
+  }
+  if(int rc = trt_trace_dev(ctx, &din, scene, tmin, tmax, &dout, nullptr)) return rc;
+  for(int k = 0; k < 8 && in->n; ++k)
+    if(dst[k])
+      TRT_HIP(ctx, hipMemcpyAsync(dst[k], ctx->d_out[k].p, bytes, hipMemcpyDeviceToHost, nullptr));
+  TRT_HIP(ctx, hipStreamSynchronize(nullptr));
+  return TRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// render
+// ------------------------------------------------------------------------------------------
+extern "C" int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
+                              const trt_scene* scene, uint32_t W, uint32_t H, uint32_t row_begin,
+                              uint32_t row_end, int camera, float* rgba, trt_hits* first_hit,
+                              trt_rendered_data* rendered, void* stream)
+{
+  if(!ctx) return TRT_E_INVALID;
+  if(!g || !pc) return fail(ctx, TRT_E_INVALID, "trt_render: NULL globals or push constants");
+  if(W == 0 || H == 0 || row_begin > row_end || row_end > H)
+    return fail(ctx, TRT_E_INVALID, "trt_render: bad size/rows W=%u H=%u rows=[%u,%u)", W, H, row_begin, row_end);
+  if((uint64_t)W * H > 0x7fffffffull)
+    return fail(ctx, TRT_E_INVALID, "trt_render: W*H=%llu exceeds 2^31-1 pixels", (unsigned long long)W * H);
+  if(camera != TRT_CAMERA_PINHOLE && camera != TRT_CAMERA_TOROIDAL)
+    return fail(ctx, TRT_E_INVALID, "trt_render: unknown camera %d", camera);
+  SceneK S;
+  if(int rc = build_scene(ctx, scene, S)) return rc;
+  TRT_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  RenderArgs  a;
+  std::memset(&a, 0, sizeof a);
+  a.g = *g;
+  a.pc = *pc;
+  a.W = W; a.H = H; a.row_begin = row_begin; a.row_end = row_end;
+  a.camera = camera;
+  a.rgba = rgba;
+  if(first_hit) a.hits = *first_hit;
+  a.rendered = rendered;
+  a.queue    = ctx->d_queue;
+  if(camera == TRT_CAMERA_TOROIDAL)
+    if(int rc = build_toro(ctx, *g, *pc, W, H, st, a.toro)) return rc;
+  if(ctx->stats_on)
+  {
+    TRT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), st));
+    a.stats           = ctx->d_stats;
+    ctx->stats_pixels = (uint64_t)(row_end - row_begin) * W;
+  }
+  if(ctx->variant == kRenderPersistent)
+    TRT_HIP(ctx, hipMemsetAsync(ctx->d_queue, 0, 64 * sizeof(unsigned int), st));
+  ctx->last_stream = st;
+  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
+  return TRT_OK;
+}
+
+extern "C" int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
+                          const trt_scene* scene, uint32_t W, uint32_t H, int camera, float* rgba_out,
+                          trt_hits* first_hit_out)
+{
+  if(!ctx) return TRT_E_INVALID;
+  TRT_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t npx = (size_t)W * H;
+  float*       d_rgba = nullptr;
+  if(rgba_out)
+  {
+    if(int rc = grow(ctx, ctx->d_rgba, npx * 16)) return rc;
+    d_rgba = (float*)ctx->d_rgba.p;
+  }
+  trt_hits dh;
+  std::memset(&dh, 0, sizeof dh);
+  void*  dst[8]  = {nullptr};
+  void** dptr[8] = {(void**)&dh.t,  (void**)&dh.px, (void**)&dh.py, (void**)&dh.pz,
+                    (void**)&dh.nx, (void**)&dh.ny, (void**)&dh.nz, (void**)&dh.id};
+  if(first_hit_out)
+  {
+    void* h[8] = {first_hit_out->t,  first_hit_out->px, first_hit_out->py, first_hit_out->pz,
+                  first_hit_out->nx, first_hit_out->ny, first_hit_out->nz, first_hit_out->id};
+    for(int k = 0; k < 8; ++k)
+      if((dst[k] = h[k]))
+      {
+        if(int rc = grow(ctx, ctx->d_out[k], npx * 4)) return rc;
+        *dptr[k] = ctx->d_out[k].p;
+      }
+  }
+  if(int rc = trt_render_dev(ctx, g, pc, scene, W, H, 0, H, camera, d_rgba, first_hit_out ? &dh : nullptr,
+                             nullptr, nullptr))
+    return rc;
+  if(rgba_out) TRT_HIP(ctx, hipMemcpyAsync(rgba_out, d_rgba, npx * 16, hipMemcpyDeviceToHost, nullptr));
+  for(int k = 0; k < 8; ++k)
+    if(dst[k]) TRT_HIP(ctx, hipMemcpyAsync(dst[k], ctx->d_out[k].p, npx * 4, hipMemcpyDeviceToHost, nullptr));
+  TRT_HIP(ctx, hipStreamSynchronize(nullptr));
+  return TRT_OK;
+}

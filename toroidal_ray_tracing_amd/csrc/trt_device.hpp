@@ -1,0 +1,378 @@
+// trt_device.hpp — device-side arithmetic of the toroidal ray tracer (gfx950 / CDNA4).
+//
+// Everything a lane needs to answer "where does this ray first meet this torus", plus the
+// closest-hit / miss / shadow-miss shader bodies of the reference restated for an analytic
+// torus.  Reference paths are relative to vk_raytracing_tutorial_KHR/
+// (REFL = ray_tracing_reflections, BEF = ray_tracing__before).
+//
+// Arithmetic contract: only IEEE-754 correctly rounded operations
+// (+ - * / sqrt fma), every fused multiply-add spelled out, translation unit compiled with
+// -ffp-contract=off.  hipcc lowers `/` and sqrtf() to correctly rounded sequences by
+// default (-fhip-fp32-correctly-rounded-divide-sqrt), so the results are reproducible on
+// any IEEE machine; tests/ check them bit for bit against a CPU restatement.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trt.h"
+
+namespace trt {
+
+// ------------------------------------------------------------------------------------------
+// scalar helpers, float / double
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float  fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float  sqrt_(float a) { return sqrtf(a); }
+__device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
+__device__ __forceinline__ float  max_(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double max_(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float  min_(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double min_(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float  abs_(float a) { return fabsf(a); }
+__device__ __forceinline__ double abs_(double a) { return fabs(a); }
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ float dot3(v3 a, v3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ v3 sub3(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3 scale3(v3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ v3 neg3(v3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ v3 normalize3(v3 a) { return scale3(a, 1.0f / sqrt_(dot3(a, a))); }
+// GLSL reflect(I,N) = I - 2·dot(N,I)·N   (REFL/shaders/raytrace.rchit:148)
+__device__ __forceinline__ v3 reflect3(v3 i, v3 n)
+{
+  const float k = 2.0f * dot3(n, i);
+  return {fma_(-k, n.x, i.x), fma_(-k, n.y, i.y), fma_(-k, n.z, i.z)};
+}
+// column-major mat4 · (x,y,z,w), rows 0..2
+__device__ __forceinline__ v3 mat4_mul(const float* m, float x, float y, float z, float w)
+{
+  v3 r;
+  r.x = fma_(m[12], w, fma_(m[8], z, fma_(m[4], y, m[0] * x)));
+  r.y = fma_(m[13], w, fma_(m[9], z, fma_(m[5], y, m[1] * x)));
+  r.z = fma_(m[14], w, fma_(m[10], z, fma_(m[6], y, m[2] * x)));
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// scene as the kernels see it (built on the host by trt_api.hip, staged into LDS per block)
+// ------------------------------------------------------------------------------------------
+template <class Real>
+struct TorusK {   // per-torus constants of the solver
+  Real cx, cy, cz;
+  Real R;
+  Real r2;      // r²
+  Real rpol;    // r/32: largest step the geometric polish may take
+  Real k0;      // R² - r²
+  Real Rb2;     // (R+r)²·(1+2⁻⁹): squared radius of the slightly inflated bounding sphere
+  Real fourR2;  // 4R²
+};
+
+struct TorusShade {  // what the closest-hit stage needs: centre, R, material index
+  float cx, cy, cz, R;
+  int   matId;
+};
+
+struct MaterialK {  // the WaveFrontMaterial fields the Phong model reads (rchit:95-155)
+  float ambient[3];
+  float diffuse[3];
+  float specular[3];
+  float shininess;
+  int   illum;
+};
+
+struct SceneK {
+  int            n_tori;
+  int            n_mat;
+  int            f64;   // 1: FP64 root solve (BASELINE config 4), FP32 I/O
+  int            pad_;
+  TorusK<float>  k32[TRT_MAX_TORI];
+  TorusK<double> k64[TRT_MAX_TORI];
+  TorusShade     shade[TRT_MAX_TORI];
+  MaterialK      mat[TRT_MAX_MATERIALS];
+};
+
+// Copy the scene constants from the kernel-argument segment into LDS, one dword per thread
+// per trip.  Reads in the hot loops then hit LDS at wave-uniform (broadcast) or
+// material-indexed addresses.
+__device__ __forceinline__ void stage_scene(SceneK* lds, const SceneK& arg)
+{
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&arg);
+  uint32_t*       dst = reinterpret_cast<uint32_t*>(lds);
+  for(uint32_t i = threadIdx.x; i < sizeof(SceneK) / 4; i += blockDim.x)
+    dst[i] = src[i];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// T1 + T2: first root of the ray–torus quartic in (tmin, tmax)
+// ------------------------------------------------------------------------------------------
+// Depressed quartic in u = t - tc (tc = parameter of closest approach to the torus centre):
+//   f(u) = A4 u⁴ + P2 u² + Q1 u + S0,  A4 = dd², P2 = 2·dd·κ - 4R²a, Q1 = -8R²b, S0 = κ² - 4R²c
+// f'' has constant sign on ≤3 pieces of the window (split at ±w); on each piece Newton's
+// iteration started where sign f = sign f'' is monotone (Fourier), so walking the pieces
+// left to right finds the smallest root or proves there is none.  The walk is written as
+// ONE loop whose every trip evaluates (f, f') at one point per lane — the lanes of a wave
+// stay convergent on the evaluation and the division although they sit in different
+// pieces/modes.
+enum : int { M_FWD = 0, M_BWD = 1, M_PROBE = 2, M_END = 3 };
+constexpr int kNewtonCap = 48;
+
+template <class Real>
+__device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
+                                                Real dz_, Real dd, Real inv_dd, Real tmin,
+                                                Real tmax, const TorusK<Real>& T, Real& t_out)
+{
+  const Real ex = ox - T.cx, ey = oy - T.cy, ez = oz - T.cz;
+  const Real n  = fma_(ez, dz_, fma_(ey, dy_, ex * dx_));
+  const Real tc = -n * inv_dd;
+  const Real qx = fma_(tc, dx_, ex), qy = fma_(tc, dy_, ey), qz = fma_(tc, dz_, ez);
+  const Real m  = fma_(qz, qz, fma_(qy, qy, qx * qx));
+  if(!(m <= T.Rb2))
+    return false;
+  const Real U  = sqrt_((T.Rb2 - m) * inv_dd);
+  const Real lo = max_(tmin - tc, -U);
+  const Real hi = min_(tmax - tc, U);
+  if(!(lo < hi))
+    return false;
+
+  const Real a     = fma_(dz_, dz_, dx_ * dx_);
+  const Real b     = fma_(qz, dz_, qx * dx_);
+  const Real c     = fma_(qz, qz, qx * qx);
+  const Real kappa = m + T.k0;
+  const Real A4    = dd * dd;
+  const Real P2    = fma_(-T.fourR2, a, (Real(2) * dd) * kappa);
+  const Real Q1    = (Real(-2) * T.fourR2) * b;
+  const Real S0    = fma_(-T.fourR2, c, kappa * kappa);
+  const Real A4x4  = Real(4) * A4;
+  const Real P2x2  = Real(2) * P2;
+  const bool split = P2 < Real(0);
+  const Real w     = split ? sqrt_(-P2 / (Real(6) * A4)) : Real(0);
+
+  Real A = lo, B = lo, x = lo, fx = Real(0), dx = Real(0), xe = lo;
+  int  sigma = 1, sref = 1, it = 0, mode = M_END;
+  bool found = false;
+  Real root  = Real(0);
+
+  for(;;)
+  {
+    const Real e1 = fma_(A4 * xe, xe, P2);
+    const Real e2 = fma_(e1, xe, Q1);
+    const Real fe = fma_(e2, xe, S0);
+    const Real g1 = fma_(A4x4 * xe, xe, P2x2);
+    const Real de = fma_(g1, xe, Q1);
+
+    bool enter = false;
+    if(mode == M_END)
+    {
+      if(!(B < hi)) break;
+      enter = true;
+    }
+    else if(mode == M_PROBE)
+    {
+      const int sb = (fe > Real(0)) ? 1 : (fe < Real(0)) ? -1 : sigma;
+      if(sb == sigma) { mode = M_BWD; x = B; fx = fe; dx = de; it = 0; sref = sb; }
+      else
+      {
+        if(!(B < hi)) break;
+        enter = true;
+      }
+    }
+    else
+    {
+      fx = fe;
+      dx = de;
+      if(mode == M_FWD && (fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref)) { found = true; root = x; break; }
+      ++it;
+    }
+
+    if(enter)
+    {
+      A = B;
+      if(split && A < -w)     { B = min_(-w, hi); sigma = 1; }
+      else if(split && A < w) { B = min_(w, hi);  sigma = -1; }
+      else                    { B = hi;           sigma = 1; }
+      if(fe == Real(0)) { found = true; root = A; break; }
+      sref = (fe > Real(0)) ? 1 : -1;
+      if(sref == sigma) { mode = M_FWD; x = A; fx = fe; dx = de; it = 0; }
+      else { mode = M_PROBE; xe = B; continue; }
+    }
+
+    if(it == kNewtonCap) { found = true; root = x; break; }
+    const Real sdx = sigma > 0 ? dx : -dx;
+    if(mode == M_FWD)
+    {
+      if(!(sdx < Real(0))) { mode = M_END; xe = B; continue; }
+      const Real xn = x - fx / dx;
+      if(!(xn < B)) { mode = M_END; xe = B; continue; }
+      if(xn == x) { found = true; root = x; break; }
+      x = xn; xe = xn;
+    }
+    else
+    {
+      if(fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref) { found = true; root = x; break; }
+      if(!(sdx > Real(0))) { found = true; root = x; break; }
+      const Real xn = x - fx / dx;
+      if(!(xn > A)) { found = true; root = A; break; }
+      if(xn == x) { found = true; root = x; break; }
+      x = xn; xe = xn;
+    }
+  }
+  if(!found)
+    return false;
+
+  // T2b: one Newton step on g(u) = (ρ-R)² + py² - r², whose rounding error scales with r²
+  // instead of R⁴; a step above r/32 (grazing, g' ≈ 0) is discarded.
+  {
+    const Real px  = fma_(root, dx_, qx), py = fma_(root, dy_, qy), pz = fma_(root, dz_, qz);
+    const Real rho = sqrt_(fma_(pz, pz, px * px));
+    const Real e   = rho - T.R;
+    const Real g   = fma_(e, e, fma_(py, py, -T.r2));
+    const Real s   = fma_(pz, dz_, px * dx_);
+    const Real gh  = fma_(e, s / rho, py * dy_);
+    const Real du  = Real(0.5) * (g / gh);
+    if(abs_(du) <= T.rpol)
+      root = root - du;
+  }
+  const Real t = root + tc;
+  if(!(t > tmin && t < tmax))
+    return false;
+  t_out = t;
+  return true;
+}
+
+// One ray against torus i in the scene's solver precision; t rounded to FP32.
+__device__ __forceinline__ bool torus_hit(const SceneK& S, int i, v3 o, v3 d, float dd, float inv_dd,
+                                          float tmin, float tmax, float& t)
+{
+  if(S.f64)
+  {
+    const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+    const double dd64 = fma_(dz, dz, fma_(dy, dy, dx * dx));
+    double       t64;
+    if(!torus_first_hit<double>(ox, oy, oz, dx, dy, dz, dd64, 1.0 / dd64, (double)tmin,
+                                (double)tmax, S.k64[i], t64))
+      return false;
+    const float tf = (float)t64;
+    if(!(tf > tmin && tf < tmax))
+      return false;
+    t = tf;
+    return true;
+  }
+  return torus_first_hit<float>(o.x, o.y, o.z, d.x, d.y, d.z, dd, inv_dd, tmin, tmax, S.k32[i], t);
+}
+
+// Closest hit over the tori — the role of traceRayEXT + BVH (REFL/shaders/raytrace.rgen:64-75).
+// Returns the torus index or -1; `tests` counts ray–torus tests.
+__device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
+                                           float& t_out, uint32_t& tests)
+{
+  const float dd = dot3(d, d), inv_dd = 1.0f / dd;
+  int   id   = -1;
+  float best = __builtin_inff();
+  for(int i = 0; i < S.n_tori; ++i)
+  {
+    float t;
+    ++tests;
+    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, t) && t < best)
+    {
+      best = t;
+      id   = i;
+    }
+  }
+  t_out = best;
+  return id;
+}
+
+// Any hit — the shadow query with gl_RayFlagsTerminateOnFirstHitEXT (REFL rchit:206-219).
+__device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
+                                        uint32_t& tests)
+{
+  const float dd = dot3(d, d), inv_dd = 1.0f / dd;
+  for(int i = 0; i < S.n_tori; ++i)
+  {
+    float t;
+    ++tests;
+    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, t))
+      return true;
+  }
+  return false;
+}
+
+// T4: outward unit normal N = normalize(P - q), q = nearest point of the centre circle
+// (role of REFL/shaders/raytrace.rchit:74-75; never flipped towards the ray).
+__device__ __forceinline__ v3 torus_normal(const TorusShade& T, v3 P)
+{
+  const v3    pl  = sub3(P, v3{T.cx, T.cy, T.cz});
+  const float rho = sqrt_(fma_(pl.z, pl.z, pl.x * pl.x));
+  const float k   = (rho - T.R) / rho;
+  return normalize3(v3{pl.x * k, pl.y, pl.z * k});
+}
+
+// ------------------------------------------------------------------------------------------
+// Phong helpers — REFL/shaders/wavefront.glsl:22-48
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ v3 compute_diffuse(const MaterialK& m, v3 L, v3 N)
+{
+  const float dotNL = max_(dot3(N, L), 0.0f);
+  v3 c = {m.diffuse[0] * dotNL, m.diffuse[1] * dotNL, m.diffuse[2] * dotNL};
+  if(m.illum >= 1)
+  {
+    c.x += m.ambient[0];
+    c.y += m.ambient[1];
+    c.z += m.ambient[2];
+  }
+  return c;
+}
+
+__device__ __forceinline__ v3 compute_specular(const MaterialK& m, v3 viewDir, v3 L, v3 N)
+{
+  if(m.illum < 2)
+    return {0.0f, 0.0f, 0.0f};
+  const float kPi        = 3.14159265f;
+  const float kShininess = max_(m.shininess, 4.0f);
+  const float kEnergy    = (2.0f + kShininess) / (2.0f * kPi);
+  const v3    V          = normalize3(neg3(viewDir));
+  const v3    R          = reflect3(neg3(L), N);
+  const float s          = kEnergy * powf(max_(dot3(V, R), 0.0f), kShininess);
+  return {m.specular[0] * s, m.specular[1] * s, m.specular[2] * s};
+}
+
+// ------------------------------------------------------------------------------------------
+// ray generation
+// ------------------------------------------------------------------------------------------
+// Per-frame constants of the toroidal camera, computed once on the host
+// (BEF/shaders/raytrace.rgen:36-53 depend only on the UBO and rho), and per-column /
+// per-row trigonometry tables (BEF rgen:25-28,56-57: alfa depends on x only, beta on y only).
+struct ToroCam {
+  float        eye[3];
+  float        rho;
+  const float* cos_a;  // [W]  cos(radians(alfa + omega))
+  const float* sin_a;  // [W]
+  const float* cos_b;  // [H]  cos(radians(beta + theta))
+  const float* sin_b;  // [H]
+};
+
+__device__ __forceinline__ void raygen(const trt_globals& g, const ToroCam& tc, uint32_t W, uint32_t H,
+                                       int camera, uint32_t x, uint32_t y, v3& origin, v3& dir)
+{
+  if(camera == TRT_CAMERA_TOROIDAL)
+  {
+    const float ca = tc.cos_a[x], sa = tc.sin_a[x], cb = tc.cos_b[y], sb = tc.sin_b[y];
+    origin = {fma_(tc.rho, ca, tc.eye[0]), tc.eye[1], fma_(tc.rho, sa, tc.eye[2])};  // BEF rgen:56
+    dir    = {ca * cb, sb, sa * cb};                                                // BEF rgen:57
+    return;
+  }
+  // pinhole, REFL/shaders/raytrace.rgen:42-48
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  const float u = px / (float)W, v = py / (float)H;
+  const float dx = u * 2.0f - 1.0f, dy = v * 2.0f - 1.0f;
+  origin       = mat4_mul(g.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f);
+  const v3 tgt = mat4_mul(g.projInverse, dx, dy, 1.0f, 1.0f);
+  const v3 tn  = normalize3(tgt);
+  dir          = mat4_mul(g.viewInverse, tn.x, tn.y, tn.z, 0.0f);
+}
+
+}  // namespace trt

@@ -1,0 +1,39 @@
+// trt_kernels.hpp — launch interface between the C ABI (trt_api.hip) and the gfx950 kernels
+// (trt_kernels.hip).  Host-side only types; no HIP runtime types leak past this header
+// except hipStream_t / hipError_t.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "trt_device.hpp"
+
+namespace trt {
+
+struct RenderArgs {
+  trt_globals g;       // GlobalUniforms, by value in the kernel-argument segment
+  trt_push    pc;      // PushConstantRay
+  ToroCam     toro;    // toroidal camera frame + device trig tables
+  uint32_t    W, H;
+  uint32_t    row_begin, row_end;
+  int         camera;
+  float*             rgba;      // [H][W][4]                      (rgen:87)
+  trt_hits           hits;      // SoA depth-0 hit record, y*W+x  (optional streams)
+  trt_rendered_data* rendered;  // AoS, x*H+y                     (BEF rgen:72-73,111-112)
+  unsigned long long* stats;    // [4]: primary, bounce, shadow tests, pixels (optional)
+  unsigned int*       queue;    // persistent kernel: global tile/pixel counter (zeroed per launch)
+};
+
+struct TraceArgs {
+  trt_rays rays;
+  trt_hits hits;
+  float    tmin, tmax;
+  unsigned long long* stats;
+};
+
+enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1 };
+
+hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
+hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
+                         hipStream_t stream);
+
+}  // namespace trt

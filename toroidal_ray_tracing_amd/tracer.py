@@ -1,0 +1,125 @@
+"""Host-side Python mirror of the reference's ray-tracing entry point, over the C ABI.
+
+``Tracer.raytrace`` plays the part of ``HelloVulkan::raytrace(cmdBuf, clearColor)``
+(vk_raytracing_tutorial_KHR/ray_tracing_reflections/hello_vulkan.cpp:913-935,
+ray_tracing__before/hello_vulkan.cpp:936-958): push constants are refreshed from the
+light state and the clear colour, then a W×H launch is issued.  All ray work happens in
+``libtrt.so`` on the GPU; this module only marshals arguments.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, lib
+
+
+class TrtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{abi.ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class Tracer:
+    """One context per device (not re-entrant), like one ``HelloVulkan`` instance."""
+
+    def __init__(self, device=0):
+        self._L = lib.load()
+        h = C.c_void_p()
+        rc = self._L.trt_create(int(device), C.byref(h))
+        if rc != 0:
+            raise TrtError(rc, (self._L.trt_last_error(None) or b"").decode())
+        self._h = h
+        self.device = int(device)
+
+    # -- lifetime ----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.trt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TrtError(rc, (self._L.trt_last_error(self._h) or b"").decode())
+
+    # -- configuration -----------------------------------------------------------------
+    def set_solver(self, precision):
+        self._check(self._L.trt_set_solver(self._h, int(precision)))
+
+    def set_render_variant(self, name):
+        self._check(self._L.trt_set_render_variant(self._h, name.encode()))
+
+    def render_variant(self):
+        return self._L.trt_get_render_variant(self._h).decode()
+
+    def enable_stats(self, on=True):
+        self._check(self._L.trt_enable_stats(self._h, int(bool(on))))
+
+    def stats(self):
+        st = abi.trt_stats()
+        self._check(self._L.trt_get_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k in ("primary_tests", "bounce_tests", "shadow_tests", "pixels")}
+
+    # -- trace(rays_in -> hits_out) ----------------------------------------------------
+    def trace(self, scene, o, d, tmin=0.001, tmax=10000.0):
+        """Host arrays: o, d of shape (n,3).  Returns a dict of SoA hit arrays."""
+        o = np.ascontiguousarray(np.asarray(o, np.float32).T)
+        d = np.ascontiguousarray(np.asarray(d, np.float32).T)
+        n = o.shape[1]
+        rays = abi.rays_struct([o[0], o[1], o[2], d[0], d[1], d[2]], n)
+        out = abi.alloc_hits(n)
+        hs = abi.hits_struct(out)
+        self._check(self._L.trt_trace(self._h, C.byref(rays), C.byref(scene.c), tmin, tmax, C.byref(hs)))
+        return out
+
+    def trace_dev(self, scene, ray_ptrs, n, hit_ptrs, tmin=0.001, tmax=10000.0, stream=0):
+        """Device pointers (ints): ray_ptrs = 6 addresses, hit_ptrs = dict name -> address."""
+        rays = abi.rays_struct([int(p) for p in ray_ptrs], n)
+        hs = abi.hits_struct({k: (int(v) if v else None) for k, v in hit_ptrs.items()})
+        self._check(self._L.trt_trace_dev(self._h, C.byref(rays), C.byref(scene.c), tmin, tmax,
+                                          C.byref(hs), C.c_void_p(int(stream))))
+
+    # -- render -------------------------------------------------------------------------
+    def render(self, scene, g, pc, W, H, camera=abi.TRT_CAMERA_PINHOLE, want_hits=True):
+        """Host buffers.  Returns (rgba (H,W,4), hits dict | None)."""
+        rgba = np.empty((H, W, 4), np.float32)
+        hits = abi.alloc_hits(W * H) if want_hits else None
+        hs = abi.hits_struct(hits) if hits is not None else None
+        self._check(self._L.trt_render(self._h, C.byref(g), C.byref(pc), C.byref(scene.c), W, H,
+                                       camera, abi.ptr(rgba), C.byref(hs) if hs is not None else None))
+        return rgba, hits
+
+    def render_dev(self, scene, g, pc, W, H, rgba_ptr, rows=None, camera=abi.TRT_CAMERA_PINHOLE,
+                   hit_ptrs=None, rendered_ptr=0, stream=0):
+        """Device buffers, asynchronous on ``stream``; rows = (begin, end) of the band to render."""
+        r0, r1 = (0, H) if rows is None else rows
+        hs = None
+        if hit_ptrs:
+            hs = abi.hits_struct({k: (int(v) if v else None) for k, v in hit_ptrs.items()})
+        self._check(self._L.trt_render_dev(self._h, C.byref(g), C.byref(pc), C.byref(scene.c), W, H,
+                                           r0, r1, camera, C.c_void_p(int(rgba_ptr) or None),
+                                           C.byref(hs) if hs is not None else None,
+                                           C.c_void_p(int(rendered_ptr) or None),
+                                           C.c_void_p(int(stream) or None)))
+
+    def raytrace(self, scene, g, light, max_depth, clear_color, W, H, rgba_ptr, camera=0, rho=0.0,
+                 **kw):
+        """Mirror of ``HelloVulkan::raytrace(cmdBuf, clearColor)``: fills PushConstantRay from
+        the light state (``light`` = dict position/intensity/type, the m_pcRaster fields) and
+        the clear colour, then launches W×H (hello_vulkan.cpp:917-931)."""
+        pc = abi.make_push(clear=clear_color, light_pos=light["position"],
+                           light_intensity=light["intensity"], light_type=light["type"],
+                           max_depth=max_depth, rho=rho)
+        self.render_dev(scene, g, pc, W, H, rgba_ptr, camera=camera, **kw)
+        return pc
