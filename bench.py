@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native toroidal ray tracer.
+
+Workload (BASELINE.json `metric`: "ray-torus intersections/sec at 4096² × 4 bounces"):
+BASELINE config 3 — single torus (R=1.0, r=0.25, mirror material), 4096×4096 primary rays,
+maxDepth 5 (= 1 primary + 4 reflection bounces, REFL/shaders/raytrace.rgen:79), FP32, pinhole
+camera at (0,1.5,-4) looking at the origin, point light (10,15,8) I=100, clear colour 1
+(SURVEY.md §8d).  One *step* = one full frame through the hot path (`trt_render_dev`):
+ray generation, closest-hit solve, Phong + shadow query, reflection bounces, and the
+rgba32f framebuffer + first-hit record written to HBM.  Inputs (camera matrices, push
+constants, scene: < 2 KB) travel as kernel arguments; outputs stay resident in HBM.
+
+`value` = primary ray–torus intersection tests per second over the whole job (pixels ×
+tori × frames ÷ wall time, max over ranks); the bounce and shadow tests executed on top are
+reported in `config.tests_per_frame` and `total_tests_per_s` but never added to `value`.
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): the SAME
+4096² frame is tiled across ranks in interleaved groups of rows (load balance: the torus
+sits in the middle rows) and the rgba32f framebuffer is all-gathered over RCCL/xGMI inside
+the timed step, as BASELINE.json north_star prescribes → "scaling": "strong".
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--variant persistent|static]
+                       [--no-cpu-baseline] [--size 4096] [--depth 5]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
+BYTES_PER_PIXEL = 16 + 28       # rgba32f + first-hit record t,P,N
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--variant", default=None, help="render kernel variant (default: library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sc, g, pc, W, H):
+    """The oracle (a scalar C port — the reference has NO CPU path) timed on this host's cores
+    on a bounded sample of the same frame: row groups of 8 spread evenly over the image."""
+    import numpy as np
+    from oracle import oracle
+    from toroidal_ray_tracing_amd import abi
+    L = oracle.lib()
+    cores = oracle.max_threads()
+    rgba = np.zeros((H, W, 4), np.float32)
+    hits = abi.alloc_hits(W * H)
+    for v in hits.values():
+        v[...] = 0
+    hs = abi.hits_struct({k: hits[k] for k in ("t", "px", "py", "pz", "nx", "ny", "nz")})
+    st = abi.trt_stats()
+
+    def run(r0, r1):
+        t0 = time.perf_counter()
+        rc = L.oracle_render(C.byref(g), C.byref(pc), C.byref(sc.c), W, H, r0, r1, 0, 0, cores,
+                             abi.ptr(rgba), C.byref(hs), None, C.byref(st))
+        assert rc == 0
+        return time.perf_counter() - t0
+
+    # calibrate on the central 64 rows, then size the sample for ~10 s of aggregate CPU work
+    dt = run(H // 2 - 32, H // 2 + 32)
+    per_row = dt / 64
+    groups = int(min(H // 8, max(8, 10.0 / max(per_row * 8 * cores, 1e-9) / 1)))
+    groups = min(groups, H // 8)
+    step = max(1, (H // 8) // groups)
+    bands = [(8 * k, 8 * k + 8) for k in range(0, H // 8, step)]
+    t = 0.0
+    px = 0
+    for r0, r1 in bands:
+        t += run(r0, r1)
+        px += (r1 - r0) * W
+    return {"value": px * sc.n_tori / t, "unit": "primary ray-torus tests/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{len(bands)} groups of 8 rows spread evenly over the {W}x{H} frame "
+                      f"({px} pixels, {t:.2f} s wall on {cores} OpenMP threads); "
+                      "build's C restatement — the reference has no CPU path"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from toroidal_ray_tracing_amd import abi, camera
+    from toroidal_ray_tracing_amd.tracer import Tracer
+    from toroidal_ray_tracing_amd import distributed as trtd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W = H = a.size
+    sc = camera.single_torus_scene()
+    g = camera.baseline_camera(W, H)
+    pc = camera.baseline_push(a.depth)
+    tr = Tracer(local)
+    if a.variant:
+        tr.set_render_variant(a.variant)
+    variant = tr.render_variant()
+
+    frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz"))
+    stream = torch.cuda.current_stream()
+
+    def step(ev=None):
+        frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, stream, events=ev)
+
+    # one counted pass (untimed): how many ray–torus tests one frame executes
+    tr.enable_stats(True)
+    step()
+    torch.cuda.synchronize()
+    st = tr.stats()
+    tr.enable_stats(False)
+    tests = torch.tensor([st["primary_tests"], st["bounce_tests"], st["shadow_tests"], st["pixels"]],
+                         dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tests)
+    n_primary, n_bounce, n_shadow, n_pixels = (int(v) for v in tests.tolist())
+    assert n_pixels == W * H and n_primary == W * H * sc.n_tori
+
+    for _ in range(a.warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(evs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # dominant kernel: the render kernel, timed live with HIP events on the launch stream
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+    px_per_launch = frame.local_pixels
+    achieved = BYTES_PER_PIXEL * px_per_launch / (kern_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(variant, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        value = a.steps * n_primary / dt
+        out = {
+            "metric": "ray-torus intersections/sec at 4096^2 x 4 bounces (primary tests/s)",
+            "value": value, "unit": "primary ray-torus tests/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3: single torus R=1 r=0.25 mirror, {W}x{H} primary rays, "
+                                   f"maxDepth {a.depth} (= {a.depth - 1} reflection bounces), FP32, pinhole",
+                       "kernel_variant": variant, "n_tori": sc.n_tori,
+                       "tests_per_frame": {"primary": n_primary, "bounce": n_bounce, "shadow": n_shadow},
+                       "tiling": frame.describe()},
+            "total_tests_per_s": a.steps * (n_primary + n_bounce + n_shadow) / dt,
+            "target_primary_tests_per_s": 2.0e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": f"render_{variant}_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL, "pixels_per_launch": px_per_launch,
+                         "note": "scalar FP32 root finding: VALU-bound, not HBM-bound (DESIGN.md §6)"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, g, pc, W, H)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    tr.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,29 @@ int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const
                    float* rgba_dev, trt_hits* first_hit_dev, trt_rendered_data* rendered_dev,
                    void* stream);
 
+/* Multi-GPU image tiling.  The frame is cut into groups of `group_rows`
+ * consecutive rows dealt round-robin to `n_parts` owners: part p owns every row y with
+ * (y / group_rows) % n_parts == p (interleaving balances the load: hit pixels cluster).
+ * compact != 0: rgba / first-hit buffers hold ONLY the owned rows, packed in order (local
+ * row ly = (y / (group_rows*n_parts)) * group_rows + y % group_rows) — the layout an
+ * all-gather wants as its send buffer.  compact == 0: full-frame buffers, row y at y.
+ * RenderedData (x*H + y) is always full-frame. */
+typedef struct trt_tiling {
+  uint32_t group_rows;
+  uint32_t n_parts;
+  uint32_t part;
+  uint32_t compact;
+} trt_tiling;
+
+/* Number of rows part `part` owns in an H-row frame under `tiling`. */
+uint32_t trt_tiling_rows(const trt_tiling* tiling, uint32_t H);
+
+/* trt_render_dev restricted to the rows `tiling` assigns to tiling->part. */
+int trt_render_tiled_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
+                         uint32_t W, uint32_t H, const trt_tiling* tiling, int camera,
+                         float* rgba_dev, trt_hits* first_hit_dev, trt_rendered_data* rendered_dev,
+                         void* stream);
+
 /* Counters of the last render or trace call made with counting enabled. */
 int trt_enable_stats(trt_ctx* ctx, int on);
 int trt_get_stats(trt_ctx* ctx, trt_stats* out); /* synchronises the ctx's last stream   */

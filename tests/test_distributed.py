@@ -1,0 +1,91 @@
+"""Multi-rank path on CPU (gloo, world_size 2): the row-group tiling, the all-gather and the
+de-interleave reproduce the single-rank frame.  The per-rank renders come from the CPU
+oracle here (there is no GPU in this container); on the GPU box the same TiledFrame logic
+runs over RCCL (tests/test_gpu_parity.py::test_tiled_render_matches_full checks the
+kernels' tiling against full-frame renders on one GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from toroidal_ray_tracing_amd import abi, camera
+from toroidal_ray_tracing_amd import distributed as trtd
+
+
+def test_owned_rows_partition():
+    for H, G, N in [(64, 8, 2), (96, 4, 3), (70, 8, 4), (16, 8, 8)]:
+        rows = [trtd.owned_rows(H, G, N, p) for p in range(N)]
+        assert sorted(sum(rows, [])) == list(range(H))
+        # matches the C ABI's count
+        from toroidal_ray_tracing_amd import lib
+        L = lib.load()
+        import ctypes as C
+        for p in range(N):
+            t = abi.trt_tiling(G, N, p, 1)
+            assert L.trt_tiling_rows(C.byref(t), H) == len(rows[p])
+    t = abi.trt_tiling(0, 2, 0, 1)
+    assert lib.load().trt_tiling_rows(C.byref(t), 64) == 0  # invalid tiling
+
+
+def test_deinterleave_inverts_tiling():
+    H, W, G, N = 48, 5, 4, 3
+    img = torch.arange(H * W * 4, dtype=torch.float32).view(H, W, 4)
+    parts = [img[trtd.owned_rows(H, G, N, p)] for p in range(N)]
+    gathered = torch.stack(parts)
+    assert torch.equal(trtd.deinterleave(gathered, H, W, G, N), img)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, G, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(3)
+        rows = trtd.owned_rows(H, G, world, rank)
+        # this rank's compact buffer: its rows of the frame, rendered band by band
+        local = np.zeros((len(rows), W, 4), np.float32)
+        for k in range(0, len(rows), G):
+            y0 = rows[k]
+            band, _, _, _ = oracle.render(sc, g, pc, W, H, rows=(y0, y0 + G), want_hits=False)
+            local[k:k + G] = band[y0:y0 + G]
+        local = torch.from_numpy(local)
+        gathered = torch.empty(world * len(rows), W, 4)
+        dist.all_gather_into_tensor(gathered, local)
+        full = trtd.deinterleave(gathered, H, W, G, world).contiguous()
+        if rank == 0:
+            want, _, _, _ = oracle.render(sc, g, pc, W, H, want_hits=False)
+            out.put(bool(np.array_equal(full.numpy(), want)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_reproduces_frame():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    W, H, G, world = 64, 64, 8, 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, G, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs)
+    assert out.get(timeout=5) is True

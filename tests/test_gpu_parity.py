@@ -304,3 +304,40 @@ def test_trace_dev_full_size_matches_render(tr):
     assert torch.equal(t_r.view(torch.int32), t_t.view(torch.int32))
     assert torch.equal(nx_r.view(torch.int32), nx_t.view(torch.int32))
     assert 0.05 < torch.isfinite(t_t).float().mean().item() < 0.5
+
+
+@pytest.mark.parametrize("variant", ["static", "persistent"])
+@pytest.mark.parametrize("parts,group", [(2, 8), (4, 8), (3, 4), (8, 8)])
+def test_tiled_render_matches_full(tr, variant, parts, group):
+    """trt_render_tiled_dev: every part renders its interleaved row groups into a compact
+    buffer; stacking + de-interleaving the parts reproduces the full-frame render bit for bit
+    (this is what each rank does before the RCCL all-gather)."""
+    import torch
+    from toroidal_ray_tracing_amd import distributed as trtd
+    W, H = 120, parts * group * 5
+    sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    tr.set_render_variant(variant)
+    try:
+        full = torch.zeros(H, W, 4, device=dev)
+        t_full = torch.zeros(H * W, device=dev)
+        tr.render_dev(sc, g, pc, W, H, full.data_ptr(), hit_ptrs={"t": t_full.data_ptr()}, stream=s)
+        gathered = torch.zeros(parts, H // parts, W, 4, device=dev)
+        t_parts = torch.zeros(parts, (H // parts) * W, device=dev)
+        for p in range(parts):
+            tiling = abi.trt_tiling(group, parts, p, 1)
+            assert tr.tiling_rows(tiling, H) == H // parts
+            tr.render_tiled_dev(sc, g, pc, W, H, tiling, gathered[p].data_ptr(),
+                                hit_ptrs={"t": t_parts[p].data_ptr()}, stream=s)
+        # non-compact: parts write straight into one full-frame buffer
+        direct = torch.zeros(H, W, 4, device=dev)
+        for p in range(parts):
+            tr.render_tiled_dev(sc, g, pc, W, H, abi.trt_tiling(group, parts, p, 0), direct.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+    finally:
+        tr.set_render_variant("static")
+    assert torch.equal(trtd.deinterleave(gathered, H, W, group, parts), full)
+    assert torch.equal(direct, full)
+    tt = trtd.deinterleave(t_parts.view(parts, H // parts, W, 1), H, W, group, parts, channels=1).reshape(-1)
+    assert torch.equal(tt.view(torch.int32), t_full.view(torch.int32))

@@ -71,6 +71,11 @@ class trt_hits(C.Structure):
                 ("nx", C.c_void_p), ("ny", C.c_void_p), ("nz", C.c_void_p), ("id", C.c_void_p)]
 
 
+class trt_tiling(C.Structure):
+    _fields_ = [("group_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32),
+                ("compact", C.c_uint32)]
+
+
 class trt_stats(C.Structure):
     _fields_ = [("primary_tests", C.c_uint64), ("bounce_tests", C.c_uint64),
                 ("shadow_tests", C.c_uint64), ("pixels", C.c_uint64)]

@@ -397,10 +397,21 @@ extern "C" int trt_trace(trt_ctx* ctx, const trt_rays* in, const trt_scene* scen
 // ------------------------------------------------------------------------------------------
 // render
 // ------------------------------------------------------------------------------------------
-extern "C" int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
-                              const trt_scene* scene, uint32_t W, uint32_t H, uint32_t row_begin,
-                              uint32_t row_end, int camera, float* rgba, trt_hits* first_hit,
-                              trt_rendered_data* rendered, void* stream)
+namespace {
+
+uint32_t tiling_rows(const trt_tiling& t, uint32_t H)
+{
+  if(t.n_parts <= 1) return H;
+  const uint32_t cycle = t.group_rows * t.n_parts;
+  const uint32_t full  = H / cycle, rem = H % cycle, start = t.part * t.group_rows;
+  uint32_t extra = 0;
+  if(rem > start) extra = rem - start < t.group_rows ? rem - start : t.group_rows;
+  return full * t.group_rows + extra;
+}
+
+int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
+                  uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, const trt_tiling* tiling,
+                  int camera, float* rgba, trt_hits* first_hit, trt_rendered_data* rendered, void* stream)
 {
   if(!ctx) return TRT_E_INVALID;
   if(!g || !pc) return fail(ctx, TRT_E_INVALID, "trt_render: NULL globals or push constants");
@@ -410,6 +421,9 @@ extern "C" int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push
     return fail(ctx, TRT_E_INVALID, "trt_render: W*H=%llu exceeds 2^31-1 pixels", (unsigned long long)W * H);
   if(camera != TRT_CAMERA_PINHOLE && camera != TRT_CAMERA_TOROIDAL)
     return fail(ctx, TRT_E_INVALID, "trt_render: unknown camera %d", camera);
+  if(tiling && (tiling->group_rows == 0 || tiling->n_parts == 0 || tiling->part >= tiling->n_parts))
+    return fail(ctx, TRT_E_INVALID, "trt_render_tiled: bad tiling group_rows=%u n_parts=%u part=%u",
+                tiling->group_rows, tiling->n_parts, tiling->part);
   SceneK S;
   if(int rc = build_scene(ctx, scene, S)) return rc;
   TRT_HIP(ctx, hipSetDevice(ctx->device));
@@ -419,6 +433,15 @@ extern "C" int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push
   a.g = *g;
   a.pc = *pc;
   a.W = W; a.H = H; a.row_begin = row_begin; a.row_end = row_end;
+  a.tile_group = 1; a.tile_parts = 1; a.tile_part = 0; a.compact = 0;
+  a.n_local_rows = row_end - row_begin;
+  if(tiling)
+  {
+    a.row_begin = 0; a.row_end = H;
+    a.tile_group = tiling->group_rows; a.tile_parts = tiling->n_parts; a.tile_part = tiling->part;
+    a.compact = tiling->compact;
+    a.n_local_rows = tiling_rows(*tiling, H);
+  }
   a.camera = camera;
   a.rgba = rgba;
   if(first_hit) a.hits = *first_hit;
@@ -430,13 +453,39 @@ extern "C" int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push
   {
     TRT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), st));
     a.stats           = ctx->d_stats;
-    ctx->stats_pixels = (uint64_t)(row_end - row_begin) * W;
+    ctx->stats_pixels = (uint64_t)a.n_local_rows * W;
   }
   if(ctx->variant == kRenderPersistent)
     TRT_HIP(ctx, hipMemsetAsync(ctx->d_queue, 0, 64 * sizeof(unsigned int), st));
   ctx->last_stream = st;
   TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
   return TRT_OK;
+}
+
+}  // namespace
+
+extern "C" uint32_t trt_tiling_rows(const trt_tiling* tiling, uint32_t H)
+{
+  if(!tiling || tiling->group_rows == 0 || tiling->n_parts == 0 || tiling->part >= tiling->n_parts) return 0;
+  return tiling_rows(*tiling, H);
+}
+
+extern "C" int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
+                              const trt_scene* scene, uint32_t W, uint32_t H, uint32_t row_begin,
+                              uint32_t row_end, int camera, float* rgba, trt_hits* first_hit,
+                              trt_rendered_data* rendered, void* stream)
+{
+  return render_common(ctx, g, pc, scene, W, H, row_begin, row_end, nullptr, camera, rgba, first_hit,
+                       rendered, stream);
+}
+
+extern "C" int trt_render_tiled_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
+                                    const trt_scene* scene, uint32_t W, uint32_t H, const trt_tiling* tiling,
+                                    int camera, float* rgba, trt_hits* first_hit,
+                                    trt_rendered_data* rendered, void* stream)
+{
+  if(ctx && !tiling) return fail(ctx, TRT_E_INVALID, "trt_render_tiled: NULL tiling");
+  return render_common(ctx, g, pc, scene, W, H, 0, H, tiling, camera, rgba, first_hit, rendered, stream);
 }
 
 extern "C" int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,

@@ -117,47 +117,63 @@ __device__ __forceinline__ void stage_scene(SceneK* lds, const SceneK& arg)
 // ONE loop whose every trip evaluates (f, f') at one point per lane — the lanes of a wave
 // stay convergent on the evaluation and the division although they sit in different
 // pieces/modes.
-enum : int { M_FWD = 0, M_BWD = 1, M_PROBE = 2, M_END = 3 };
+enum : int { M_FWD = 0, M_BWD = 1, M_PROBE = 2, M_END = 3, M_DONE = 4 };
 constexpr int kNewtonCap = 48;
 
+// One ray-vs-torus test as a resumable state machine: setup() does T1 (returns false when the
+// bounding sphere / parameter window culls the ray), every step() evaluates (f, f') once and
+// advances the walk (returns false when the test is decided), finish() polishes the root and
+// applies the open interval (tmin, tmax).  A lane can park a TorusTest in registers between
+// step() calls — the persistent kernel relies on that.
 template <class Real>
-__device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
-                                                Real dz_, Real dd, Real inv_dd, Real tmin,
-                                                Real tmax, const TorusK<Real>& T, Real& t_out)
-{
-  const Real ex = ox - T.cx, ey = oy - T.cy, ez = oz - T.cz;
-  const Real n  = fma_(ez, dz_, fma_(ey, dy_, ex * dx_));
-  const Real tc = -n * inv_dd;
-  const Real qx = fma_(tc, dx_, ex), qy = fma_(tc, dy_, ey), qz = fma_(tc, dz_, ez);
-  const Real m  = fma_(qz, qz, fma_(qy, qy, qx * qx));
-  if(!(m <= T.Rb2))
-    return false;
-  const Real U  = sqrt_((T.Rb2 - m) * inv_dd);
-  const Real lo = max_(tmin - tc, -U);
-  const Real hi = min_(tmax - tc, U);
-  if(!(lo < hi))
-    return false;
+struct TorusTest {
+  // quartic and window
+  Real A4, P2, Q1, S0, w, hi, tc;
+  Real qx, qy, qz;     // point of closest approach to the torus centre (local frame)
+  // walk
+  Real A, B, x, fx, dx, xe, root;
+  int  sigma, sref, it, mode;
+  bool split, found;
 
-  const Real a     = fma_(dz_, dz_, dx_ * dx_);
-  const Real b     = fma_(qz, dz_, qx * dx_);
-  const Real c     = fma_(qz, qz, qx * qx);
-  const Real kappa = m + T.k0;
-  const Real A4    = dd * dd;
-  const Real P2    = fma_(-T.fourR2, a, (Real(2) * dd) * kappa);
-  const Real Q1    = (Real(-2) * T.fourR2) * b;
-  const Real S0    = fma_(-T.fourR2, c, kappa * kappa);
-  const Real A4x4  = Real(4) * A4;
-  const Real P2x2  = Real(2) * P2;
-  const bool split = P2 < Real(0);
-  const Real w     = split ? sqrt_(-P2 / (Real(6) * A4)) : Real(0);
-
-  Real A = lo, B = lo, x = lo, fx = Real(0), dx = Real(0), xe = lo;
-  int  sigma = 1, sref = 1, it = 0, mode = M_END;
-  bool found = false;
-  Real root  = Real(0);
-
-  for(;;)
+  __device__ __forceinline__ bool setup(Real ox, Real oy, Real oz, Real dx_, Real dy_, Real dz_,
+                                        Real dd, Real inv_dd, Real tmin, Real tmax,
+                                        const TorusK<Real>& T)
   {
+    const Real ex = ox - T.cx, ey = oy - T.cy, ez = oz - T.cz;
+    const Real n  = fma_(ez, dz_, fma_(ey, dy_, ex * dx_));
+    tc = -n * inv_dd;
+    qx = fma_(tc, dx_, ex); qy = fma_(tc, dy_, ey); qz = fma_(tc, dz_, ez);
+    const Real m = fma_(qz, qz, fma_(qy, qy, qx * qx));
+    mode = M_DONE;
+    found = false;
+    if(!(m <= T.Rb2))
+      return false;
+    const Real U  = sqrt_((T.Rb2 - m) * inv_dd);
+    const Real lo = max_(tmin - tc, -U);
+    hi = min_(tmax - tc, U);
+    if(!(lo < hi))
+      return false;
+    const Real a     = fma_(dz_, dz_, dx_ * dx_);
+    const Real b     = fma_(qz, dz_, qx * dx_);
+    const Real c     = fma_(qz, qz, qx * qx);
+    const Real kappa = m + T.k0;
+    A4    = dd * dd;
+    P2    = fma_(-T.fourR2, a, (Real(2) * dd) * kappa);
+    Q1    = (Real(-2) * T.fourR2) * b;
+    S0    = fma_(-T.fourR2, c, kappa * kappa);
+    split = P2 < Real(0);
+    w     = split ? sqrt_(-P2 / (Real(6) * A4)) : Real(0);
+    A = lo; B = lo; x = lo; xe = lo;
+    fx = Real(0); dx = Real(0); root = Real(0);
+    sigma = 1; sref = 1; it = 0; mode = M_END;
+    return true;
+  }
+
+  // One evaluation of (f, f') at xe, then the transitions of the walk.  Returns true while
+  // the test is undecided.
+  __device__ __forceinline__ bool step()
+  {
+    const Real A4x4 = Real(4) * A4, P2x2 = Real(2) * P2;
     const Real e1 = fma_(A4 * xe, xe, P2);
     const Real e2 = fma_(e1, xe, Q1);
     const Real fe = fma_(e2, xe, S0);
@@ -167,7 +183,7 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
     bool enter = false;
     if(mode == M_END)
     {
-      if(!(B < hi)) break;
+      if(!(B < hi)) { mode = M_DONE; return false; }
       enter = true;
     }
     else if(mode == M_PROBE)
@@ -176,7 +192,7 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
       if(sb == sigma) { mode = M_BWD; x = B; fx = fe; dx = de; it = 0; sref = sb; }
       else
       {
-        if(!(B < hi)) break;
+        if(!(B < hi)) { mode = M_DONE; return false; }
         enter = true;
       }
     }
@@ -184,7 +200,7 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
     {
       fx = fe;
       dx = de;
-      if(mode == M_FWD && (fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref)) { found = true; root = x; break; }
+      if(mode == M_FWD && (fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref)) return hit(x);
       ++it;
     }
 
@@ -194,39 +210,46 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
       if(split && A < -w)     { B = min_(-w, hi); sigma = 1; }
       else if(split && A < w) { B = min_(w, hi);  sigma = -1; }
       else                    { B = hi;           sigma = 1; }
-      if(fe == Real(0)) { found = true; root = A; break; }
+      if(fe == Real(0)) return hit(A);
       sref = (fe > Real(0)) ? 1 : -1;
       if(sref == sigma) { mode = M_FWD; x = A; fx = fe; dx = de; it = 0; }
-      else { mode = M_PROBE; xe = B; continue; }
+      else { mode = M_PROBE; xe = B; return true; }
     }
 
-    if(it == kNewtonCap) { found = true; root = x; break; }
+    if(it == kNewtonCap) return hit(x);
     const Real sdx = sigma > 0 ? dx : -dx;
     if(mode == M_FWD)
     {
-      if(!(sdx < Real(0))) { mode = M_END; xe = B; continue; }
+      if(!(sdx < Real(0))) { mode = M_END; xe = B; return true; }
       const Real xn = x - fx / dx;
-      if(!(xn < B)) { mode = M_END; xe = B; continue; }
-      if(xn == x) { found = true; root = x; break; }
+      if(!(xn < B)) { mode = M_END; xe = B; return true; }
+      if(xn == x) return hit(x);
       x = xn; xe = xn;
     }
     else
     {
-      if(fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref) { found = true; root = x; break; }
-      if(!(sdx > Real(0))) { found = true; root = x; break; }
+      if(fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref) return hit(x);
+      if(!(sdx > Real(0))) return hit(x);
       const Real xn = x - fx / dx;
-      if(!(xn > A)) { found = true; root = A; break; }
-      if(xn == x) { found = true; root = x; break; }
+      if(!(xn > A)) return hit(A);
+      if(xn == x) return hit(x);
       x = xn; xe = xn;
     }
+    return true;
   }
-  if(!found)
-    return false;
+
+  __device__ __forceinline__ bool hit(Real r) { found = true; root = r; mode = M_DONE; return false; }
 
   // T2b: one Newton step on g(u) = (ρ-R)² + py² - r², whose rounding error scales with r²
-  // instead of R⁴; a step above r/32 (grazing, g' ≈ 0) is discarded.
+  // instead of R⁴ (a step above r/32 — grazing, g' ≈ 0 — is discarded); then t = u + tc and
+  // the open-interval test of the closest-hit query.
+  __device__ __forceinline__ bool finish(Real dx_, Real dy_, Real dz_, Real tmin, Real tmax,
+                                         const TorusK<Real>& T, Real& t_out) const
   {
-    const Real px  = fma_(root, dx_, qx), py = fma_(root, dy_, qy), pz = fma_(root, dz_, qz);
+    if(!found)
+      return false;
+    Real r = root;
+    const Real px  = fma_(r, dx_, qx), py = fma_(r, dy_, qy), pz = fma_(r, dz_, qz);
     const Real rho = sqrt_(fma_(pz, pz, px * px));
     const Real e   = rho - T.R;
     const Real g   = fma_(e, e, fma_(py, py, -T.r2));
@@ -234,49 +257,82 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
     const Real gh  = fma_(e, s / rho, py * dy_);
     const Real du  = Real(0.5) * (g / gh);
     if(abs_(du) <= T.rpol)
-      root = root - du;
+      r = r - du;
+    const Real t = r + tc;
+    if(!(t > tmin && t < tmax))
+      return false;
+    t_out = t;
+    return true;
   }
-  const Real t = root + tc;
-  if(!(t > tmin && t < tmax))
+};
+
+template <class Real>
+__device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
+                                                Real dz_, Real dd, Real inv_dd, Real tmin,
+                                                Real tmax, const TorusK<Real>& T, Real& t_out)
+{
+  TorusTest<Real> q;
+  if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))
     return false;
-  t_out = t;
+  while(q.step()) {}
+  return q.finish(dx_, dy_, dz_, tmin, tmax, T, t_out);
+}
+
+// Solver constants of torus i in the kernel's precision.
+template <class Real> __device__ __forceinline__ const TorusK<Real>& torus_k(const SceneK& S, int i);
+template <> __device__ __forceinline__ const TorusK<float>&  torus_k<float>(const SceneK& S, int i) { return S.k32[i]; }
+template <> __device__ __forceinline__ const TorusK<double>& torus_k<double>(const SceneK& S, int i) { return S.k64[i]; }
+
+// Per-ray constants of a query in the solver precision (FP32 I/O, FP32 or FP64 solve).
+template <class Real>
+struct RayK {
+  Real ox, oy, oz, dx, dy, dz, dd, inv_dd, tmin, tmax;
+  __device__ __forceinline__ void set(v3 o, v3 d, float tmin_, float tmax_)
+  {
+    ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
+    dd     = fma_(dz, dz, fma_(dy, dy, dx * dx));
+    inv_dd = Real(1) / dd;
+    tmin = tmin_; tmax = tmax_;
+  }
+};
+
+// Result of a test in the solver precision -> FP32 t; rounding may land on the open bounds.
+__device__ __forceinline__ bool round_t(float t, float, float, float& out) { out = t; return true; }
+__device__ __forceinline__ bool round_t(double t, float tmin, float tmax, float& out)
+{
+  const float tf = (float)t;
+  if(!(tf > tmin && tf < tmax))
+    return false;
+  out = tf;
   return true;
 }
 
-// One ray against torus i in the scene's solver precision; t rounded to FP32.
-__device__ __forceinline__ bool torus_hit(const SceneK& S, int i, v3 o, v3 d, float dd, float inv_dd,
-                                          float tmin, float tmax, float& t)
+// One ray against torus i; t rounded to FP32.
+template <class Real>
+__device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t)
 {
-  if(S.f64)
-  {
-    const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
-    const double dd64 = fma_(dz, dz, fma_(dy, dy, dx * dx));
-    double       t64;
-    if(!torus_first_hit<double>(ox, oy, oz, dx, dy, dz, dd64, 1.0 / dd64, (double)tmin,
-                                (double)tmax, S.k64[i], t64))
-      return false;
-    const float tf = (float)t64;
-    if(!(tf > tmin && tf < tmax))
-      return false;
-    t = tf;
-    return true;
-  }
-  return torus_first_hit<float>(o.x, o.y, o.z, d.x, d.y, d.z, dd, inv_dd, tmin, tmax, S.k32[i], t);
+  Real tt;
+  if(!torus_first_hit<Real>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.dd, r.inv_dd, r.tmin, r.tmax,
+                            torus_k<Real>(S, i), tt))
+    return false;
+  return round_t(tt, tmin, tmax, t);
 }
 
 // Closest hit over the tori — the role of traceRayEXT + BVH (REFL/shaders/raytrace.rgen:64-75).
 // Returns the torus index or -1; `tests` counts ray–torus tests.
+template <class Real>
 __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
                                            float& t_out, uint32_t& tests)
 {
-  const float dd = dot3(d, d), inv_dd = 1.0f / dd;
+  RayK<Real> r;
+  r.set(o, d, tmin, tmax);
   int   id   = -1;
   float best = __builtin_inff();
   for(int i = 0; i < S.n_tori; ++i)
   {
     float t;
     ++tests;
-    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, t) && t < best)
+    if(torus_hit<Real>(S, i, r, tmin, tmax, t) && t < best)
     {
       best = t;
       id   = i;
@@ -287,15 +343,17 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
 }
 
 // Any hit — the shadow query with gl_RayFlagsTerminateOnFirstHitEXT (REFL rchit:206-219).
+template <class Real>
 __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
                                         uint32_t& tests)
 {
-  const float dd = dot3(d, d), inv_dd = 1.0f / dd;
+  RayK<Real> r;
+  r.set(o, d, tmin, tmax);
   for(int i = 0; i < S.n_tori; ++i)
   {
     float t;
     ++tests;
-    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, t))
+    if(torus_hit<Real>(S, i, r, tmin, tmax, t))
       return true;
   }
   return false;

@@ -14,7 +14,12 @@ struct RenderArgs {
   trt_push    pc;      // PushConstantRay
   ToroCam     toro;    // toroidal camera frame + device trig tables
   uint32_t    W, H;
-  uint32_t    row_begin, row_end;
+  uint32_t    row_begin, row_end;  // contiguous band (tile_parts <= 1)
+  // interleaved row groups (multi-GPU tiling): this launch owns the rows y with
+  // (y / tile_group) % tile_parts == tile_part; n_local_rows of them.  compact != 0: the rgba
+  // and first-hit streams are indexed by LOCAL row (buffers hold only this part's rows).
+  uint32_t    tile_group, tile_parts, tile_part, compact;
+  uint32_t    n_local_rows;
   int         camera;
   float*             rgba;      // [H][W][4]                      (rgen:87)
   trt_hits           hits;      // SoA depth-0 hit record, y*W+x  (optional streams)
@@ -31,6 +36,7 @@ struct TraceArgs {
 };
 
 enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1 };
+constexpr int kPersistentBlocksPerCU = 4;  // 256-thread blocks resident per CU (16 waves/CU)
 
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,

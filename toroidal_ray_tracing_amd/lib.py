@@ -30,6 +30,11 @@ SYMBOLS = {
                                  C.POINTER(abi.trt_scene), C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_uint32, C.c_int, C.c_void_p, C.POINTER(abi.trt_hits),
                                  C.c_void_p, C.c_void_p]),
+    "trt_render_tiled_dev": (C.c_int, [C.c_void_p, C.POINTER(abi.trt_globals), C.POINTER(abi.trt_push),
+                                       C.POINTER(abi.trt_scene), C.c_uint32, C.c_uint32,
+                                       C.POINTER(abi.trt_tiling), C.c_int, C.c_void_p,
+                                       C.POINTER(abi.trt_hits), C.c_void_p, C.c_void_p]),
+    "trt_tiling_rows": (C.c_uint32, [C.POINTER(abi.trt_tiling), C.c_uint32]),
     "trt_enable_stats": (C.c_int, [C.c_void_p, C.c_int]),
     "trt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(abi.trt_stats)]),
     "trt_set_render_variant": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -47,6 +52,16 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME
+        # libamdhip64.so.7 — the same SONAME libtrt.so links against).  Two HIP runtimes in one
+        # process cannot both own the GPU, so torch must be loaded FIRST: the dynamic loader
+        # then resolves libtrt.so's dependency to the runtime torch already mapped, and device
+        # pointers / streams are shared between the two.  Without torch installed libtrt.so
+        # simply uses /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -113,6 +113,21 @@ class Tracer:
                                            C.c_void_p(int(rendered_ptr) or None),
                                            C.c_void_p(int(stream) or None)))
 
+    def render_tiled_dev(self, scene, g, pc, W, H, tiling, rgba_ptr, camera=abi.TRT_CAMERA_PINHOLE,
+                         hit_ptrs=None, rendered_ptr=0, stream=0):
+        """Rows owned by ``tiling.part`` only (multi-GPU tiling, include/trt.h ``trt_tiling``)."""
+        hs = None
+        if hit_ptrs:
+            hs = abi.hits_struct({k: (int(v) if v else None) for k, v in hit_ptrs.items()})
+        self._check(self._L.trt_render_tiled_dev(self._h, C.byref(g), C.byref(pc), C.byref(scene.c), W, H,
+                                                 C.byref(tiling), camera, C.c_void_p(int(rgba_ptr) or None),
+                                                 C.byref(hs) if hs is not None else None,
+                                                 C.c_void_p(int(rendered_ptr) or None),
+                                                 C.c_void_p(int(stream) or None)))
+
+    def tiling_rows(self, tiling, H):
+        return int(self._L.trt_tiling_rows(C.byref(tiling), H))
+
     def raytrace(self, scene, g, light, max_depth, clear_color, W, H, rgba_ptr, camera=0, rho=0.0,
                  **kw):
         """Mirror of ``HelloVulkan::raytrace(cmdBuf, clearColor)``: fills PushConstantRay from
