@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--variant", default=None, help="render kernel variant (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hits", default="tpn", choices=["tpn", "none"], help="first-hit record streams to write")
+    ap.add_argument("--center", default="0,0,0", help="camera look-at point (diagnostics; default = BASELINE)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
     return ap.parse_args()
 
@@ -111,14 +113,15 @@ def main():
 
     W = H = a.size
     sc = camera.single_torus_scene()
-    g = camera.baseline_camera(W, H)
+    g = camera.baseline_camera(W, H) if a.center == "0,0,0" else camera.globals_for(
+        (0.0, 1.5, -4.0), tuple(float(v) for v in a.center.split(",")), W, H)
     pc = camera.baseline_push(a.depth)
     tr = Tracer(local)
     if a.variant:
         tr.set_render_variant(a.variant)
     variant = tr.render_variant()
 
-    frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz"))
+    frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else ())
     stream = torch.cuda.current_stream()
 
     def step(ev=None):

@@ -152,7 +152,7 @@ def check_render(tr, oracle, sc, g, pc, W, H, cam, precision=abi.TRT_SOLVE_F32):
     return rgba, hits, wstats
 
 
-@pytest.mark.parametrize("variant", ["static", "persistent"])
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
 @pytest.mark.parametrize("name", list(RENDERS))
 def test_render_parity(tr, oracle, name, variant):
     W, H = 200, 136   # not multiples of the 8x8 tile
@@ -169,7 +169,7 @@ def test_render_parity(tr, oracle, name, variant):
     assert st == {**wstats}
 
 
-@pytest.mark.parametrize("variant", ["static", "persistent"])
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
 def test_render_fp64_nested(tr, oracle, variant):
     W, H = 160, 120
     sc, g, pc = camera.nested_tori_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
@@ -201,7 +201,7 @@ def test_render_vs_golden(tr, name, cam):
     np.testing.assert_allclose(hits["t"][m], z["hit_t"][m], rtol=1e-5)
 
 
-@pytest.mark.parametrize("variant", ["static", "persistent"])
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
 def test_render_dev_rows_and_rendered_data(tr, oracle, variant):
     """Device-pointer entry point: row bands tile the frame; RenderedData AoS at x*H+y."""
     import torch
@@ -236,7 +236,7 @@ def test_render_dev_rows_and_rendered_data(tr, oracle, variant):
     assert np.all(out[:10] == 0) and np.all(out[20:] == 0) and np.all(out[10:20, :, 3] == 1)
 
 
-@pytest.mark.parametrize("variant", ["static", "persistent"])
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
 def test_full_size_properties(tr, variant):
     """BASELINE config 3 (4096², maxDepth 5 = 4 bounces): properties that need no oracle.
     Left-right mirror symmetry of the scene is NOT used (the light breaks it); instead:
@@ -306,7 +306,7 @@ def test_trace_dev_full_size_matches_render(tr):
     assert 0.05 < torch.isfinite(t_t).float().mean().item() < 0.5
 
 
-@pytest.mark.parametrize("variant", ["static", "persistent"])
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
 @pytest.mark.parametrize("parts,group", [(2, 8), (4, 8), (3, 4), (8, 8)])
 def test_tiled_render_matches_full(tr, variant, parts, group):
     """trt_render_tiled_dev: every part renders its interleaved row groups into a compact

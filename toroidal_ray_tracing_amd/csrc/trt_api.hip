@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -50,6 +51,7 @@ struct trt_ctx {
 
   // staging for the host-pointer entry points (grow-only, freed in trt_destroy)
   DevBuf d_in[6], d_out[8], d_rgba, d_rendered;
+  DevBuf d_tiles;  // LIVE + CLEAR tile lists of the persistent kernel
 };
 
 namespace {
@@ -269,7 +271,7 @@ extern "C" void trt_destroy(trt_ctx* ctx)
   if(ctx->d_stats) (void)hipFree(ctx->d_stats);
   if(ctx->d_queue) (void)hipFree(ctx->d_queue);
   if(ctx->h_toro) (void)hipHostFree(ctx->h_toro);
-  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered};
+  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered, &ctx->d_tiles};
   for(DevBuf* b : all)
     if(b->p) (void)hipFree(b->p);
   for(DevBuf& b : ctx->d_in)
@@ -293,6 +295,7 @@ extern "C" int trt_set_render_variant(trt_ctx* ctx, const char* name)
   if(!ctx || !name) return TRT_E_INVALID;
   if(!std::strcmp(name, "static")) ctx->variant = kRenderStatic;
   else if(!std::strcmp(name, "persistent")) ctx->variant = kRenderPersistent;
+  else if(!std::strcmp(name, "listed")) ctx->variant = kRenderListed;
   else return fail(ctx, TRT_E_INVALID, "trt_set_render_variant: unknown variant '%s'", name);
   return TRT_OK;
 }
@@ -300,7 +303,7 @@ extern "C" int trt_set_render_variant(trt_ctx* ctx, const char* name)
 extern "C" const char* trt_get_render_variant(const trt_ctx* ctx)
 {
   if(!ctx) return "";
-  return ctx->variant == kRenderPersistent ? "persistent" : "static";
+  return ctx->variant == kRenderPersistent ? "persistent" : ctx->variant == kRenderListed ? "listed" : "static";
 }
 
 extern "C" int trt_enable_stats(trt_ctx* ctx, int on)
@@ -455,10 +458,32 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     a.stats           = ctx->d_stats;
     ctx->stats_pixels = (uint64_t)a.n_local_rows * W;
   }
-  if(ctx->variant == kRenderPersistent)
+  if(ctx->variant != kRenderStatic)
+  {
+    if(W > 8u * 65535u || a.n_local_rows > 8u * 65535u)
+      return fail(ctx, TRT_E_INVALID, "trt_render: persistent variant packs tile coordinates in 16 bits (W, rows <= 524280)");
+    const size_t n_tiles = (size_t)((W + 7) / 8) * ((a.n_local_rows + 7) / 8);
+    if(int rc = grow(ctx, ctx->d_tiles, 2 * n_tiles * sizeof(uint32_t))) return rc;
+    a.tiles_live  = (uint32_t*)ctx->d_tiles.p;
+    a.tiles_clear = a.tiles_live + n_tiles;
+    // tile culling needs tiles that are 8 contiguous image rows, and no per-pixel ray export
+    a.tile_cull = (rendered == nullptr && (a.tile_parts <= 1 || a.tile_group % 8 == 0)) ? 1u : 0u;
+    if(getenv("TRT_NO_TILE_CULL")) a.tile_cull = 0;
+    uintptr_t bits = 0;
+    const void* hp[8] = {a.hits.t, a.hits.px, a.hits.py, a.hits.pz, a.hits.nx, a.hits.ny, a.hits.nz, a.hits.id};
+    for(const void* q : hp) bits |= (uintptr_t)q;
+    a.vec4_ok = (W % 4 == 0 && (bits & 15) == 0) ? 1u : 0u;
     TRT_HIP(ctx, hipMemsetAsync(ctx->d_queue, 0, 64 * sizeof(unsigned int), st));
+  }
   ctx->last_stream = st;
   TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
+  if(ctx->variant != kRenderStatic && getenv("TRT_DEBUG_TILES"))
+  {
+    unsigned int q[2];
+    TRT_HIP(ctx, hipStreamSynchronize(st));
+    TRT_HIP(ctx, hipMemcpy(q, ctx->d_queue, sizeof q, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[trt] tiles: live=%u clear=%u (cull=%u)\n", q[0], q[1], a.tile_cull);
+  }
   return TRT_OK;
 }
 

@@ -130,8 +130,8 @@ struct TorusTest {
   // quartic and window
   Real A4, P2, Q1, S0, w, hi, tc;
   Real qx, qy, qz;     // point of closest approach to the torus centre (local frame)
-  // walk
-  Real A, B, x, fx, dx, xe, root;
+  // walk: piece [A,B] with sign(f'') = sigma; xe = point to evaluate next (END/PROBE: xe == B)
+  Real A, B, xe, root;
   int  sigma, sref, it, mode;
   bool split, found;
 
@@ -162,83 +162,80 @@ struct TorusTest {
     Q1    = (Real(-2) * T.fourR2) * b;
     S0    = fma_(-T.fourR2, c, kappa * kappa);
     split = P2 < Real(0);
-    w     = split ? sqrt_(-P2 / (Real(6) * A4)) : Real(0);
-    A = lo; B = lo; x = lo; xe = lo;
-    fx = Real(0); dx = Real(0); root = Real(0);
+    const Real k6 = (inv_dd * inv_dd) * Real(1.0 / 6.0);  // 1/(6·A4) without a division
+    w     = split ? sqrt_(-P2 * k6) : Real(0);
+    A = lo; B = lo; xe = lo; root = Real(0);
     sigma = 1; sref = 1; it = 0; mode = M_END;
     return true;
   }
 
-  // One evaluation of (f, f') at xe, then the transitions of the walk.  Returns true while
-  // the test is undecided.
+  // One evaluation of (f, f') at xe, then the transitions of the walk — written as straight-
+  // line predicated code (compares + selects, one division) so that the lanes of a wave, which
+  // sit in different pieces and modes, execute ONE instruction stream per trip.
+  // Returns true while the test is undecided.
+  //
+  //   END    xe == B was evaluated after a forward run found no root in [A,B]: next piece.
+  //   PROBE  xe == B was evaluated because sign f(A) = -sigma: a root exists in the piece iff
+  //          sign f(B) = sigma; then iterate backward from B, else next piece.
+  //   FWD    Newton from the left end; monotone while a root lies ahead, otherwise sigma·f'
+  //          turns >= 0 or the iterate leaves the piece (-> END).
+  //   BWD    Newton from the right end onto the single root of the piece.
   __device__ __forceinline__ bool step()
   {
-    const Real A4x4 = Real(4) * A4, P2x2 = Real(2) * P2;
-    const Real e1 = fma_(A4 * xe, xe, P2);
-    const Real e2 = fma_(e1, xe, Q1);
-    const Real fe = fma_(e2, xe, S0);
-    const Real g1 = fma_(A4x4 * xe, xe, P2x2);
-    const Real de = fma_(g1, xe, Q1);
+    const Real u  = xe;
+    const Real e1 = fma_(A4 * u, u, P2);
+    const Real e2 = fma_(e1, u, Q1);
+    const Real fe = fma_(e2, u, S0);
+    const Real g1 = fma_((Real(4) * A4) * u, u, Real(2) * P2);
+    const Real de = fma_(g1, u, Q1);
 
-    bool enter = false;
-    if(mode == M_END)
-    {
-      if(!(B < hi)) { mode = M_DONE; return false; }
-      enter = true;
-    }
-    else if(mode == M_PROBE)
-    {
-      const int sb = (fe > Real(0)) ? 1 : (fe < Real(0)) ? -1 : sigma;
-      if(sb == sigma) { mode = M_BWD; x = B; fx = fe; dx = de; it = 0; sref = sb; }
-      else
-      {
-        if(!(B < hi)) { mode = M_DONE; return false; }
-        enter = true;
-      }
-    }
-    else
-    {
-      fx = fe;
-      dx = de;
-      if(mode == M_FWD && (fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref)) return hit(x);
-      ++it;
-    }
+    const bool mEnd = mode == M_END, mProbe = mode == M_PROBE, mFwd = mode == M_FWD, mBwd = mode == M_BWD;
+    const bool pos = fe > Real(0), neg = fe < Real(0), zer = fe == Real(0);
+    const int  sfe = pos ? 1 : -1;
+    const int  sb  = pos ? 1 : (neg ? -1 : sigma);
 
-    if(enter)
-    {
-      A = B;
-      if(split && A < -w)     { B = min_(-w, hi); sigma = 1; }
-      else if(split && A < w) { B = min_(w, hi);  sigma = -1; }
-      else                    { B = hi;           sigma = 1; }
-      if(fe == Real(0)) return hit(A);
-      sref = (fe > Real(0)) ? 1 : -1;
-      if(sref == sigma) { mode = M_FWD; x = A; fx = fe; dx = de; it = 0; }
-      else { mode = M_PROBE; xe = B; return true; }
-    }
+    // leaving the piece at B (END, or PROBE without a sign change) / entering the next one
+    const bool probe_ok = mProbe && sb == sigma;
+    const bool leave    = mEnd || (mProbe && !probe_ok);
+    const bool more     = B < hi;
+    const bool enter    = leave && more;
+    const bool c1 = split && B < -w, c2 = split && B < w;
+    const Real Bn = c1 ? min_(-w, hi) : (c2 ? min_(w, hi) : hi);
+    const int  sn = (c2 && !c1) ? -1 : 1;
+    const bool e_hit = enter && zer;                 // the piece end is itself a root
+    const bool e_fwd = enter && !zer && sfe == sn;
+    const bool e_prb = enter && !zer && sfe != sn;
 
-    if(it == kNewtonCap) return hit(x);
-    const Real sdx = sigma > 0 ? dx : -dx;
-    if(mode == M_FWD)
-    {
-      if(!(sdx < Real(0))) { mode = M_END; xe = B; return true; }
-      const Real xn = x - fx / dx;
-      if(!(xn < B)) { mode = M_END; xe = B; return true; }
-      if(xn == x) return hit(x);
-      x = xn; xe = xn;
-    }
-    else
-    {
-      if(fx == Real(0) || ((fx > Real(0)) ? 1 : -1) != sref) return hit(x);
-      if(!(sdx > Real(0))) return hit(x);
-      const Real xn = x - fx / dx;
-      if(!(xn > A)) return hit(A);
-      if(xn == x) return hit(x);
-      x = xn; xe = xn;
-    }
-    return true;
+    const Real A2     = enter ? B : A;
+    const Real B2     = enter ? Bn : B;
+    const int  sigma2 = enter ? sn : sigma;
+    const int  sref2  = enter ? sfe : (probe_ok ? sb : sref);
+    const int  it2    = (mFwd || mBwd) ? it + 1 : 0;
+
+    // Newton step from u (the current iterate is always the point just evaluated)
+    const bool f_flip = mFwd && (zer || sfe != sref);      // rounding carried f across zero
+    const bool isF    = (mFwd && !f_flip) || e_fwd;
+    const bool isB    = mBwd || probe_ok;
+    const bool cap    = (isF || isB) && it2 == kNewtonCap;
+    const Real sdx    = sigma2 > 0 ? de : -de;
+    const Real xn     = u - fe / de;
+    const bool f_no   = isF && !cap && (!(sdx < Real(0)) || !(xn < B2));  // no root in [u,B]
+    const bool f_cv   = isF && !cap && !f_no && xn == u;
+    const bool b_stop = (zer || sfe != sref2) || !(sdx > Real(0));
+    const bool b_left = !(xn > A2);
+    const bool b_hitx = isB && !cap && (b_stop || (!b_left && xn == u));
+    const bool b_hitA = isB && !cap && !b_stop && b_left;
+    const bool go     = (isF && !cap && !f_no && !f_cv) || (isB && !cap && !b_stop && !b_left && xn != u);
+
+    const bool hit_x = e_hit || f_flip || cap || f_cv || b_hitx;
+    const bool done  = (leave && !more) || hit_x || b_hitA;
+    found = hit_x || b_hitA;
+    root  = b_hitA ? A2 : u;
+    A = A2; B = B2; sigma = sigma2; sref = sref2; it = it2;
+    xe   = (e_prb || f_no) ? B2 : (go ? xn : u);
+    mode = done ? M_DONE : (e_prb ? M_PROBE : (f_no ? M_END : (isF ? M_FWD : M_BWD)));
+    return !done;
   }
-
-  __device__ __forceinline__ bool hit(Real r) { found = true; root = r; mode = M_DONE; return false; }
 
   // T2b: one Newton step on g(u) = (ρ-R)² + py² - r², whose rounding error scales with r²
   // instead of R⁴ (a step above r/32 — grazing, g' ≈ 0 — is discarded); then t = u + tc and
@@ -254,8 +251,8 @@ struct TorusTest {
     const Real e   = rho - T.R;
     const Real g   = fma_(e, e, fma_(py, py, -T.r2));
     const Real s   = fma_(pz, dz_, px * dx_);
-    const Real gh  = fma_(e, s / rho, py * dy_);
-    const Real du  = Real(0.5) * (g / gh);
+    const Real gh  = fma_(e, s, (py * dy_) * rho);  // ρ·g'/2
+    const Real du  = Real(0.5) * ((g * rho) / gh);
     if(abs_(du) <= T.rpol)
       r = r - du;
     const Real t = r + tc;

@@ -6,15 +6,17 @@
 //   render_persistent_kernel  persistent wavefronts over a global work queue: the bounce
 //                             loop is flattened into per-lane queries (closest-hit, shadow,
 //                             bounce); a lane whose pixel is finished is refilled at once
-//                             (ballot + popcount compaction, one atomic per 256-pixel
-//                             chunk per wave), so every trip of the solve loop works on 64
-//                             live ray–torus tests.
+//                             (ballot + popcount compaction from the wave's round-robin tile
+//                             sequence), so every trip of the solve loop works on 64 live
+//                             ray–torus tests.
 //
 // One lane = one ray.  Scene constants are staged into LDS once per block.  No MFMA: the
 // work is scalar FP32/FP64 root finding.  Compiled with -ffp-contract=off (see
 // trt_device.hpp for the arithmetic contract).  Every kernel is instantiated for the FP32
 // and the FP64 root solve (BASELINE config 4); I/O is FP32 in both.
 #include "trt_kernels.hpp"
+
+#include <cstdlib>
 
 namespace trt {
 
@@ -115,6 +117,17 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v)
     atomicAdd(dst, (unsigned long long)v);
 }
 
+// Stage the launch arguments into LDS next to the scene.  Kept in the kernel-argument segment
+// they would be pinned in ~150 SGPRs for the whole persistent loop (hipcc loads kernargs once
+// and never rematerialises them), and the spills cost a dozen v_readlane per output store.
+__device__ __forceinline__ void stage_args(RenderArgs* lds, const RenderArgs& arg)
+{
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&arg);
+  uint32_t*       dst = reinterpret_cast<uint32_t*>(lds);
+  for(uint32_t i = threadIdx.x; i < sizeof(RenderArgs) / 4; i += blockDim.x)
+    dst[i] = src[i];
+}
+
 constexpr float kTMin = 0.001f;    // rgen:51, rchit:114
 constexpr float kTMax = 10000.0f;  // rgen:52
 
@@ -157,84 +170,202 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
 // ------------------------------------------------------------------------------------------
 // render, static mapping: lane ↔ pixel for the whole bounce loop
 // ------------------------------------------------------------------------------------------
+// One pixel, start to finish, on one lane: the reference's raygen main() with the closest-hit,
+// miss and shadow-miss shaders inlined (REFL/shaders/raytrace.rgen:40-88).
 template <class Real>
+__device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a, uint32_t x, uint32_t y, uint32_t ly,
+                                            uint32_t& n_primary, uint32_t& n_bounce, uint32_t& n_shadow)
+{
+  const size_t oi = out_index(a, x, y, ly);
+  v3 origin, direction;
+  raygen(a.g, a.toro, a.W, a.H, a.camera, x, y, origin, direction);
+  float4* rd = a.rendered ? reinterpret_cast<float4*>(&a.rendered[(size_t)x * a.H + y]) : nullptr;  // BEF rgen:72
+  if(rd)
+  {
+    rd[2] = make_float4(origin.x, origin.y, origin.z, 1.0f);               // BEF rgen:56,72
+    rd[3] = make_float4(direction.x, direction.y, direction.z, 0.0f);      // BEF rgen:57,73
+  }
+
+  int depth = 0, done = 1;                                                 // rgen:54,57
+  v3  attenuation = {1.0f, 1.0f, 1.0f};                                    // rgen:56
+  v3  hitValue    = {0.0f, 0.0f, 0.0f};                                    // rgen:61
+  for(;;)                                                                  // rgen:62
+  {
+    v3    prdHit, nextO = origin, nextD = direction;
+    float t;
+    const int id = closest_hit<Real>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce);
+    if(id < 0)
+    {
+      prdHit = {a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f};  // rmiss:37
+      if(depth == 0)
+      {
+        store_first_hit(a, oi, t, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);  // BEF rmiss:21
+        if(rd) rd[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+      }
+    }
+    else
+    {
+      HitState h;
+      hit_begin(S, a.pc, id, t, origin, direction, h);
+      if(depth == 0)                                                       // BEF rgen:94-97
+      {
+        store_first_hit(a, oi, t, h.P, h.N, id);
+        if(rd) rd[0] = make_float4(h.P.x, h.P.y, h.P.z, 1.0f);             // BEF rgen:112
+      }
+      bool shadowed = false;
+      if(h.wantShadow)
+        shadowed = any_hit<Real>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow);  // rchit:114-131
+      prdHit = hit_end(S, h, direction, shadowed, attenuation, done, nextO, nextD);
+    }
+    hitValue.x = fma_(prdHit.x, attenuation.x, hitValue.x);                // rgen:76
+    hitValue.y = fma_(prdHit.y, attenuation.y, hitValue.y);
+    hitValue.z = fma_(prdHit.z, attenuation.z, hitValue.z);
+    depth++;                                                               // rgen:78
+    if(done == 1 || depth >= a.pc.maxDepth)                                // rgen:79
+      break;
+    origin    = nextO;                                                     // rgen:82
+    direction = nextD;                                                     // rgen:83
+    done      = 1;                                                         // rgen:84
+  }
+  const float4 c = make_float4(hitValue.x, hitValue.y, hitValue.z, 1.0f);
+  if(a.rgba) reinterpret_cast<float4*>(a.rgba)[oi] = c;                    // rgen:87
+  if(rd) rd[1] = c;                                                        // BEF rgen:111
+}
+
+template <class Real, int TW>
 __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, const RenderArgs a)
 {
   __shared__ SceneK S;
   stage_scene(&S, scene);
 
-  // 8×8 pixel tile per wavefront: neighbouring lanes trace neighbouring rays
+  // TW×TH pixel tile per wavefront (TW·TH = 64): neighbouring lanes trace neighbouring rays;
+  // a row of the tile is TW·16 B of rgba and TW·4 B of every first-hit stream
+  constexpr int TH = 64 / TW;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t tiles_x = (a.W + 7) >> 3;
+  const uint32_t tiles_x = (a.W + TW - 1) / TW;
   const uint32_t tile    = blockIdx.x * (blockDim.x >> 6) + wave;
-  const uint32_t x  = (tile % tiles_x) * 8 + (lane & 7);
-  const uint32_t ly = (tile / tiles_x) * 8 + (lane >> 3);
+  const uint32_t x  = (tile % tiles_x) * TW + (lane % TW);
+  const uint32_t ly = (tile / tiles_x) * TH + (lane / TW);
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
-
   if(x < a.W && ly < a.n_local_rows)
-  {
-    const uint32_t y = image_row(a, ly);
-    const size_t   oi = out_index(a, x, y, ly);
-    v3 origin, direction;
-    raygen(a.g, a.toro, a.W, a.H, a.camera, x, y, origin, direction);
-    float4* rd = a.rendered ? reinterpret_cast<float4*>(&a.rendered[(size_t)x * a.H + y]) : nullptr;  // BEF rgen:72
-    if(rd)
-    {
-      rd[2] = make_float4(origin.x, origin.y, origin.z, 1.0f);               // BEF rgen:56,72
-      rd[3] = make_float4(direction.x, direction.y, direction.z, 0.0f);      // BEF rgen:57,73
-    }
-
-    int depth = 0, done = 1;                                                 // rgen:54,57
-    v3  attenuation = {1.0f, 1.0f, 1.0f};                                    // rgen:56
-    v3  hitValue    = {0.0f, 0.0f, 0.0f};                                    // rgen:61
-    for(;;)                                                                  // rgen:62
-    {
-      v3    prdHit, nextO = origin, nextD = direction;
-      float t;
-      const int id = closest_hit<Real>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce);
-      if(id < 0)
-      {
-        prdHit = {a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f};  // rmiss:37
-        if(depth == 0)
-        {
-          store_first_hit(a, oi, t, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);  // BEF rmiss:21
-          if(rd) rd[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        }
-      }
-      else
-      {
-        HitState h;
-        hit_begin(S, a.pc, id, t, origin, direction, h);
-        if(depth == 0)                                                       // BEF rgen:94-97
-        {
-          store_first_hit(a, oi, t, h.P, h.N, id);
-          if(rd) rd[0] = make_float4(h.P.x, h.P.y, h.P.z, 1.0f);             // BEF rgen:112
-        }
-        bool shadowed = false;
-        if(h.wantShadow)
-          shadowed = any_hit<Real>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow);  // rchit:114-131
-        prdHit = hit_end(S, h, direction, shadowed, attenuation, done, nextO, nextD);
-      }
-      hitValue.x = fma_(prdHit.x, attenuation.x, hitValue.x);                // rgen:76
-      hitValue.y = fma_(prdHit.y, attenuation.y, hitValue.y);
-      hitValue.z = fma_(prdHit.z, attenuation.z, hitValue.z);
-      depth++;                                                               // rgen:78
-      if(done == 1 || depth >= a.pc.maxDepth)                                // rgen:79
-        break;
-      origin    = nextO;                                                     // rgen:82
-      direction = nextD;                                                     // rgen:83
-      done      = 1;                                                         // rgen:84
-    }
-    const float4 c = make_float4(hitValue.x, hitValue.y, hitValue.z, 1.0f);
-    if(a.rgba) reinterpret_cast<float4*>(a.rgba)[oi] = c;                    // rgen:87
-    if(rd) rd[1] = c;                                                        // BEF rgen:111
-  }
+    trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
   if(a.stats)
   {
     wave_add(&a.stats[0], n_primary);
     wave_add(&a.stats[1], n_bounce);
     wave_add(&a.stats[2], n_shadow);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile classification: which 8×8 tiles can be answered without tracing a single ray
+// ------------------------------------------------------------------------------------------
+// One lane per tile.  A tile is CLEAR when every primary ray of the tile provably misses the
+// (inflated) bounding sphere of every torus: its pixels are then misses at depth 0 —
+// rgba = (clearColor·0.8, 1), first hit = (inf, 0, 0, -1) — exactly what the per-pixel path
+// would compute (raytrace.rmiss:37, BEF rmiss:21), because TorusTest::setup() culls on the
+// same sphere.  The bound is conservative: with the tile's centre ray (oc, dc) and its four
+// corner-pixel rays, every ray of the tile starts within Δo of oc and points within θ of dc
+// (θ = k · max corner chord; the angle to dc is quasi-convex on the image plane, so its
+// maximum over the pixel rectangle sits at a corner; k covers chord→angle and, for the
+// toroidal camera, the non-planar patch).  The distance from a torus centre C to the ray's
+// line is 1-Lipschitz in the origin and |C-o|-Lipschitz in the direction angle, hence
+//     dist >= dl - Δo - (L + Δo)·θ,   dl = dist(C, centre line), L = |C - oc|,
+// and the tile is clear when that exceeds the sphere radius by 1.6 % + 1e-5·(L+1) — three
+// orders of magnitude above the FP32 rounding of the per-pixel test.  Anything doubtful
+// (NaN, wide tiles, origin near the sphere) is LIVE.  Tiles are appended to two compact lists
+// (one wave-aggregated atomic per list per wave); order within the lists is irrelevant.
+__device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs& a, uint32_t x0, uint32_t ty, uint32_t width)
+{
+  const uint32_t x1 = min(x0 + width - 1, a.W - 1);
+  const uint32_t l0 = ty * 8, l1 = min(l0 + 7, a.n_local_rows - 1);
+  const uint32_t y0 = image_row(a, l0), y1 = image_row(a, l1);
+  const uint32_t xs[5] = {(x0 + x1 + 1) >> 1, x0, x1, x0, x1};
+  const uint32_t ys[5] = {(y0 + y1 + 1) >> 1, y0, y0, y1, y1};
+  v3    oc = {0.0f, 0.0f, 0.0f}, dc = {0.0f, 0.0f, 1.0f};
+  float chord2 = 0.0f, shift2 = 0.0f;
+#pragma unroll
+  for(int i = 0; i < 5; ++i)
+  {
+    v3 o, d;
+    raygen(a.g, a.toro, a.W, a.H, a.camera, xs[i], ys[i], o, d);
+    d = normalize3(d);
+    if(i == 0) { oc = o; dc = d; }
+    else
+    {
+      const v3 dd = sub3(d, dc), od = sub3(o, oc);
+      chord2 = max_(chord2, dot3(dd, dd));
+      shift2 = max_(shift2, dot3(od, od));
+    }
+  }
+  const float theta = (a.camera == TRT_CAMERA_PINHOLE ? 1.6f : 2.0f) * sqrt_(chord2);
+  const float dO    = 1.5f * sqrt_(shift2);
+  if(!(theta < 0.5f))
+    return false;
+  for(int i = 0; i < S.n_tori; ++i)
+  {
+    const v3    v  = sub3(v3{S.shade[i].cx, S.shade[i].cy, S.shade[i].cz}, oc);
+    const float L2 = dot3(v, v), s = dot3(v, dc);
+    const float L  = sqrt_(L2), dl = sqrt_(max_(L2 - s * s, 0.0f));
+    const float rb = sqrt_(S.k32[i].Rb2);
+    if(!(dl - dO - (L + dO) * theta > rb * 1.015625f + 1e-5f * (L + 1.0f)))
+      return false;
+  }
+  return true;
+}
+
+constexpr int kClassifyThreads = 1024;
+constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8×8 tiles = 32×8 pixels
+
+// One lane per MACRO tile (32×8 pixels: one 128-B line of every first-hit stream per row).
+// A clear macro tile becomes ONE entry of the CLEAR list (written later with full-line
+// dwordx4 stores); any other macro tile contributes its 8×8 tiles to the LIVE list.
+__global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const SceneK scene, const RenderArgs a)
+{
+  // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
+  // per list per 1024 macro tiles (a returning atomic on a shared word costs ≈11 ns under
+  // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare)
+  __shared__ uint32_t wave_cnt[2][kClassifyThreads / 64];
+  __shared__ uint32_t block_base[2];
+  const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
+  const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool     valid = t < macro_x * tiles_y;
+  const uint32_t mx = t % macro_x, ty = t / macro_x;
+  const uint32_t tx0 = mx * kMacroTiles;
+  const uint32_t ntile = valid ? min(kMacroTiles, tiles_x - tx0) : 0u;   // 8×8 tiles inside the image
+  const bool     clear = valid && a.tile_cull && tile_is_clear(scene, a, tx0 * 8, ty, kMacroTiles * 8);
+  const uint32_t nlive = clear ? 0u : ntile;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // wave-level exclusive prefix of nlive (0..4) and of clear (0/1)
+  uint32_t live_pre = nlive, clear_pre = clear ? 1u : 0u;
+#pragma unroll
+  for(int off = 1; off < 64; off <<= 1)
+  {
+    const uint32_t l = __shfl_up(live_pre, off, 64), c = __shfl_up(clear_pre, off, 64);
+    if(lane >= (uint32_t)off) { live_pre += l; clear_pre += c; }
+  }
+  if(lane == 63) { wave_cnt[0][wave] = live_pre; wave_cnt[1][wave] = clear_pre; }
+  live_pre -= nlive;
+  clear_pre -= clear ? 1u : 0u;
+  __syncthreads();
+  if(threadIdx.x < 2)
+  {
+    uint32_t sum = 0;
+    for(uint32_t w = 0; w < kClassifyThreads / 64; ++w)
+    {
+      const uint32_t c = wave_cnt[threadIdx.x][w];
+      wave_cnt[threadIdx.x][w] = sum;  // exclusive prefix over the block's waves
+      sum += c;
+    }
+    block_base[threadIdx.x] = sum ? atomicAdd(&a.queue[threadIdx.x], sum) : 0u;
+  }
+  __syncthreads();
+  if(clear)
+    a.tiles_clear[block_base[1] + wave_cnt[1][wave] + clear_pre] = tx0 | (ty << 16);
+  for(uint32_t j = 0; j < nlive; ++j)
+    a.tiles_live[block_base[0] + wave_cnt[0][wave] + live_pre + j] = (tx0 + j) | (ty << 16);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -245,31 +376,104 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
 // 1..2·maxDepth queries, each a loop over the tori.  Here that recursion is flattened: a lane
 // owns one *query* at a time (closest-hit or shadow) and inside it one ray–torus *test*
 // (a TorusTest state machine).  Each trip of the outer loop
-//   (A) advances every lane until it has a live test: finished queries run their shader
-//       stage (miss / closest-hit / shadow-miss) and spawn the next query or finish the
-//       pixel; idle lanes are compacted with a ballot and refilled from the wave's chunk of
-//       the global pixel queue; tests culled by the bounding sphere are skipped at once;
+//   (0) writes one CLEAR tile (constant miss record, 9 coalesced store instructions): the
+//       HBM-bound part of the frame drains in the background of the VALU-bound part;
+//   (A) advances the lanes: finished queries run their shader stage (miss / closest-hit /
+//       shadow-miss) and spawn the next query or finish the pixel; idle lanes are compacted
+//       with a ballot and refilled from the wave's LIVE tiles; tests culled by the bounding
+//       sphere are skipped at once.  A round of (A) runs only for >= kMinBatch lanes (or
+//       when nothing is in flight), so the shader/refill code never runs for a few stragglers
+//       while the other lanes wait;
 //   (B) runs the solve loop — every lane evaluates (f, f') of ITS test, whatever pixel,
 //       depth or query kind it belongs to;
 //   (C) folds the finished tests into their queries.
+// Work distribution: the two tile lists are dealt round-robin to the persistent waves (wave g
+// takes entries g, g+G, g+2G, …): no shared counter in the loop (one device-wide atomic word
+// saturates at ≈88 dequeues/µs, MI355X_MICROARCH.md "dequeue"), and since the LIVE list is
+// compact every wave gets the same number of non-trivial tiles.
 enum : int { K_NONE = 0, K_CLOSEST = 1, K_SHADOW = 2 };
-constexpr uint32_t kChunk = 256;  // pixels per queue grab: 4 horizontally adjacent 8×8 tiles
+constexpr uint32_t kMinBatch = 24;
+
+// Writes the constant miss record of one CLEAR macro tile (32×8 pixels) and returns the number
+// of image pixels this lane wrote.  Lane l = (row r = l >> 3, q = l & 7).  Each first-hit
+// stream is stored as ONE dwordx4 per lane (pixels 4q..4q+3 of row r): a wave instruction
+// writes 8 full 128-B lines.  rgba takes 4 dwordx4 per lane, instruction j writing pixels
+// 8j + q: again 8 full lines per instruction.  (Narrow stores are what bounds a streaming
+// writer on this chip: a dword store of 8×32-B row pieces is issue-limited to ≈3 B/clk/CU.)
+__device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t packed, uint32_t lane, float4 c)
+{
+  const uint32_t x0 = (packed & 0xffffu) * 8, ly = (packed >> 16) * 8 + (lane >> 3), q = lane & 7;
+  if(ly >= a.n_local_rows)
+    return 0;
+  const uint32_t y   = image_row(a, ly);
+  const size_t   row = (size_t)(a.compact ? ly : y) * a.W;
+  uint32_t n = 0;
+  // rgba: pixel 8j + q
+#pragma unroll
+  for(uint32_t j = 0; j < 4; ++j)
+  {
+    const uint32_t x = x0 + 8 * j + q;
+    if(x < a.W)
+    {
+      if(a.rgba) reinterpret_cast<float4*>(a.rgba)[row + x] = c;
+      ++n;
+    }
+  }
+  // first-hit streams: pixels 4q .. 4q+3
+  const uint32_t xs = x0 + 4 * q;
+  if(a.vec4_ok && xs + 3 < a.W)
+  {
+    const float  inf = __builtin_inff();
+    const float4 tv = make_float4(inf, inf, inf, inf), zv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const size_t i = row + xs;
+    if(a.hits.t) *reinterpret_cast<float4*>(a.hits.t + i) = tv;
+    if(a.hits.px) *reinterpret_cast<float4*>(a.hits.px + i) = zv;
+    if(a.hits.py) *reinterpret_cast<float4*>(a.hits.py + i) = zv;
+    if(a.hits.pz) *reinterpret_cast<float4*>(a.hits.pz + i) = zv;
+    if(a.hits.nx) *reinterpret_cast<float4*>(a.hits.nx + i) = zv;
+    if(a.hits.ny) *reinterpret_cast<float4*>(a.hits.ny + i) = zv;
+    if(a.hits.nz) *reinterpret_cast<float4*>(a.hits.nz + i) = zv;
+    if(a.hits.id) *reinterpret_cast<int4*>(a.hits.id + i) = make_int4(-1, -1, -1, -1);
+  }
+  else
+  {
+    for(uint32_t k = 0; k < 4; ++k)
+      if(xs + k < a.W)
+        store_first_hit(a, row + xs + k, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);
+  }
+  return n;
+}
 
 template <class Real>
-__global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK scene, const RenderArgs a)
+__global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK scene, const RenderArgs a_arg)
 {
-  __shared__ SceneK S;
+  __shared__ SceneK     S;
+  __shared__ RenderArgs A_lds;
+  stage_args(&A_lds, a_arg);
   stage_scene(&S, scene);
+  const RenderArgs& a = A_lds;
 
   const uint32_t lane    = threadIdx.x & 63;
-  const uint32_t tiles_x = (a.W + 7) >> 3;
-  const uint32_t tiles_y = (a.n_local_rows + 7) >> 3;
-  const uint32_t P       = tiles_x * tiles_y * 64;  // pixel slots incl. the ragged border
   const int      n_tori  = S.n_tori;
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(a.queue[0]);
+  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
+  const float4   clear_c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f,
+                                       a.pc.clearColor[2] * 0.8f, 1.0f);  // rmiss:37, rgen:76 (×1 + 0), rgen:87
 
-  // wave-uniform queue state
-  uint32_t chunk_next = 0, chunk_end = 0;
-  bool     exhausted  = false;
+  // Queue state.  Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k caches the
+  // wave's k-th entry of the current batch of 64 (one gather load per 64 tiles) and entries
+  // are broadcast with v_readlane: the steady-state loop issues NO global loads, so no
+  // s_waitcnt vmcnt ever drains the stream of output stores behind it.
+  const uint32_t my_live_n  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;   // entries owned
+  const uint32_t my_clear_n = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
+  uint32_t k_live = 0, k_clear = 0;  // next owned entry (wave-uniform)
+  uint32_t live_cache  = lane < my_live_n ? a.tiles_live[g_wave + (size_t)lane * n_waves] : 0u;
+  uint32_t clear_cache = lane < my_clear_n ? a.tiles_clear[g_wave + (size_t)lane * n_waves] : 0u;
+  bool     exhausted = my_live_n == 0;
+  uint32_t cur = __builtin_amdgcn_readlane(live_cache, 0);
+  uint32_t next_in_tile = 0;  // pixels of the current tile handed out
 
   // lane state: pixel payload (rgen:54-61)
   uint32_t px = 0, py = 0;       // pixel: x and image row
@@ -297,19 +501,34 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
 
   for(;;)
   {
+    // ------------------------------ (0) clear tiles ----------------------------------------
+    // one per trip while there is tracing to do; all of them once the wave has none left
+    while(k_clear < my_clear_n)
+    {
+      if((k_clear & 63u) == 0 && k_clear)
+        clear_cache = k_clear + lane < my_clear_n ? a.tiles_clear[g_wave + (size_t)(k_clear + lane) * n_waves] : 0u;
+      const uint32_t packed = __builtin_amdgcn_readlane(clear_cache, k_clear & 63u);
+      n_primary += clear_macro(a, packed, lane, clear_c) * (uint32_t)n_tori;
+      ++k_clear;
+      if(!(exhausted && !__any(inflight || kind != K_NONE)))
+        break;
+    }
+
     // ------------------------------ (A) advance -----------------------------------------
     for(;;)
     {
       const bool needs = !inflight && !(kind == K_NONE && exhausted);
-      if(!__any(needs))
+      const uint32_t n_needs = (uint32_t)__popcll(__ballot(needs));
+      if(n_needs == 0 || (n_needs < kMinBatch && __any(inflight)))
         break;
 
       // A1: shader stages of finished queries
-      if(needs && kind != K_NONE && (ti >= n_tori || shadow_hit))
+      const bool stage = needs && kind != K_NONE && (ti >= n_tori || shadow_hit);
+      if(__any(stage))
       {
         bool have_prd = false, shadowed = false, do_end = false;
         v3   prdHit = {0.0f, 0.0f, 0.0f};
-        if(kind == K_CLOSEST)
+        if(stage && kind == K_CLOSEST)
         {
           float4* rd = a.rendered ? reinterpret_cast<float4*>(&a.rendered[(size_t)px * a.H + py]) : nullptr;
           if(best_id < 0)
@@ -345,7 +564,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
               do_end = true;
           }
         }
-        else
+        else if(stage)
         {
           do_end   = true;
           shadowed = shadow_hit;
@@ -384,30 +603,22 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
         }
       }
 
-      // A2: compaction — refill idle lanes from the wave's chunk of the global queue
+      // A2: compaction — idle lanes (ballot) take the next pixels of the wave's current tile
+      // in order (rank among the idle lanes = mbcnt of the ballot); a drained tile is replaced
+      // by the wave's next LIVE tile.
       for(;;)
       {
         const unsigned long long want = __ballot(kind == K_NONE && !exhausted);
         if(want == 0)
           break;
-        if(chunk_next == chunk_end)
-        {
-          uint32_t base = 0;
-          if(lane == 0)
-            base = atomicAdd(a.queue, kChunk);
-          base = __builtin_amdgcn_readfirstlane(base);
-          if(base >= P) { exhausted = true; break; }
-          chunk_next = base;
-          chunk_end  = base + kChunk < P ? base + kChunk : P;
-        }
-        const uint32_t avail = chunk_end - chunk_next;
+        const uint32_t avail = 64u - next_in_tile;
         const uint32_t rank  = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
         const uint32_t nwant = (uint32_t)__popcll(want);
         if(kind == K_NONE && rank < avail)
         {
-          const uint32_t p = chunk_next + rank, tile = p >> 6, within = p & 63;
-          const uint32_t x = (tile % tiles_x) * 8 + (within & 7), ly = (tile / tiles_x) * 8 + (within >> 3);
+          const uint32_t within = next_in_tile + rank;
+          const uint32_t x = (cur & 0xffffu) * 8 + (within & 7), ly = (cur >> 16) * 8 + (within >> 3);
           if(x < a.W && ly < a.n_local_rows)
           {
             px = x;
@@ -428,7 +639,19 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
             rk.set(qo, qd, kTMin, kTMax);
           }
         }
-        chunk_next += nwant < avail ? nwant : avail;
+        next_in_tile += nwant < avail ? nwant : avail;
+        if(next_in_tile == 64u)
+        {
+          next_in_tile = 0;
+          ++k_live;
+          exhausted = k_live >= my_live_n;
+          if(!exhausted)
+          {
+            if((k_live & 63u) == 0)
+              live_cache = k_live + lane < my_live_n ? a.tiles_live[g_wave + (size_t)(k_live + lane) * n_waves] : 0u;
+            cur = __builtin_amdgcn_readlane(live_cache, k_live & 63u);
+          }
+        }
       }
 
       // A3: set up the next test of every lane that has a query but no test
@@ -445,7 +668,11 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
       }
     }
     if(!__any(inflight))
-      break;  // queue drained and every pixel finished
+    {
+      if(k_clear < my_clear_n || __any(kind != K_NONE))
+        continue;  // clear tiles, or stragglers waiting for a batch, are left
+      break;       // both lists drained and every pixel finished
+    }
 
     // ------------------------------ (B) solve ---------------------------------------------
     while(__any(inflight))
@@ -482,6 +709,51 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
 }
 
 // ------------------------------------------------------------------------------------------
+// render, tile lists + static lane↔pixel mapping ("listed")
+// ------------------------------------------------------------------------------------------
+// After tile_classify_kernel: every wave walks its share of the LIVE list (entries g, g+G, …),
+// tracing each 8×8 tile with the plain per-lane bounce loop, then writes its share of the CLEAR
+// macro tiles.  The grid is several times larger than the number of resident blocks, so the
+// hardware workgroup dispatcher balances the (very uneven) tile costs; the clear stores of
+// blocks that finish early overlap the solve of the others.
+template <class Real>
+__global__ __launch_bounds__(256) void render_listed_kernel(const SceneK scene, const RenderArgs a)
+{
+  __shared__ SceneK S;
+  stage_scene(&S, scene);
+  const uint32_t lane    = threadIdx.x & 63;
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(a.queue[0]);
+  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
+  uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
+
+  for(uint32_t e = g_wave; e < n_live; e += n_waves)
+  {
+    const uint32_t packed = __builtin_amdgcn_readfirstlane(a.tiles_live[e]);
+    const uint32_t x = (packed & 0xffffu) * 8 + (lane & 7), ly = (packed >> 16) * 8 + (lane >> 3);
+    if(x < a.W && ly < a.n_local_rows)
+      trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+  }
+  const float4 clear_c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f,
+                                     a.pc.clearColor[2] * 0.8f, 1.0f);
+  for(uint32_t base = g_wave; base < n_clear; base += 64u * n_waves)
+  {
+    // lane k prefetches the wave's k-th entry of this batch: no load between the stores
+    const uint32_t mine = base + lane * n_waves < n_clear ? a.tiles_clear[base + (size_t)lane * n_waves] : 0u;
+    const uint32_t cnt  = (n_clear - base + n_waves - 1) / n_waves;
+    for(uint32_t k = 0; k < (cnt < 64u ? cnt : 64u); ++k)
+      n_primary += clear_macro(a, __builtin_amdgcn_readlane(mine, k), lane, clear_c) * (uint32_t)S.n_tori;
+  }
+  if(a.stats)
+  {
+    wave_add(&a.stats[0], n_primary);
+    wave_add(&a.stats[1], n_bounce);
+    wave_add(&a.stats[2], n_shadow);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream)
@@ -503,23 +775,48 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
   if(a.n_local_rows == 0 || a.W == 0)
     return hipSuccess;
   const uint64_t tiles = (uint64_t)((a.W + 7) / 8) * ((a.n_local_rows + 7) / 8);
-  if(v == kRenderPersistent)
+  if(v == kRenderPersistent || v == kRenderListed)
   {
-    // resident grid: every CU gets kBlocksPerCU blocks of 4 waves; never more blocks than chunks
-    const uint64_t chunks = (tiles * 64 + kChunk - 1) / kChunk;
-    const uint64_t cap    = (uint64_t)n_cus * kPersistentBlocksPerCU;
-    const uint32_t grid   = (uint32_t)((chunks + 3) / 4 < cap ? (chunks + 3) / 4 : cap);
+    // 1. classify the tiles (one lane per tile) into the LIVE and CLEAR lists
+    const uint64_t macros = (uint64_t)(((a.W + 7) / 8 + kMacroTiles - 1) / kMacroTiles) * ((a.n_local_rows + 7) / 8);
+    hipLaunchKernelGGL(tile_classify_kernel, dim3((uint32_t)((macros + kClassifyThreads - 1) / kClassifyThreads)),
+                       dim3(kClassifyThreads), 0, stream, scene, a);
+    // 2. resident grid: kPersistentBlocksPerCU blocks of 4 waves per CU, never more waves than tiles
+    uint64_t cap = (uint64_t)n_cus * kPersistentBlocksPerCU;
+    if(const char* e = getenv("TRT_PERSIST_BLOCKS")) cap = (uint64_t)atoll(e);
+    if(v == kRenderListed)
+    {
+      uint64_t lcap = (uint64_t)n_cus * 32;  // oversubscribed: the dispatcher balances the tile costs
+      if(const char* e = getenv("TRT_LISTED_BLOCKS")) lcap = (uint64_t)atoll(e);
+      const uint32_t lgrid = (uint32_t)((tiles + 3) / 4 < lcap ? (tiles + 3) / 4 : lcap);
+      if(scene.f64)
+        hipLaunchKernelGGL(render_listed_kernel<double>, dim3(lgrid), dim3(256), 0, stream, scene, a);
+      else
+        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid), dim3(256), 0, stream, scene, a);
+      return hipGetLastError();
+    }
+    const uint32_t grid = (uint32_t)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);
     if(scene.f64)
       hipLaunchKernelGGL(render_persistent_kernel<double>, dim3(grid), dim3(256), 0, stream, scene, a);
     else
       hipLaunchKernelGGL(render_persistent_kernel<float>, dim3(grid), dim3(256), 0, stream, scene, a);
     return hipGetLastError();
   }
-  const uint32_t grid = (uint32_t)((tiles + 3) / 4);
+  // wave tile shape of the static kernel: TRT_TILE = 8x8 (default) | 16x4 | 32x2 | 64x1
+  int tw = 8;
+  if(const char* e = getenv("TRT_TILE")) tw = atoi(e);
+  if(tw != 8 && tw != 16 && tw != 32 && tw != 64) tw = 8;
+  const uint64_t stiles = (uint64_t)((a.W + tw - 1) / tw) * ((a.n_local_rows + 64 / tw - 1) / (64 / tw));
+  const uint32_t grid = (uint32_t)((stiles + 3) / 4);
+#define TRT_LAUNCH_STATIC(REAL, TW_) \
+  hipLaunchKernelGGL((render_static_kernel<REAL, TW_>), dim3(grid), dim3(256), 0, stream, scene, a)
   if(scene.f64)
-    hipLaunchKernelGGL(render_static_kernel<double>, dim3(grid), dim3(256), 0, stream, scene, a);
-  else
-    hipLaunchKernelGGL(render_static_kernel<float>, dim3(grid), dim3(256), 0, stream, scene, a);
+    TRT_LAUNCH_STATIC(double, 8);
+  else if(tw == 16) TRT_LAUNCH_STATIC(float, 16);
+  else if(tw == 32) TRT_LAUNCH_STATIC(float, 32);
+  else if(tw == 64) TRT_LAUNCH_STATIC(float, 64);
+  else TRT_LAUNCH_STATIC(float, 8);
+#undef TRT_LAUNCH_STATIC
   return hipGetLastError();
 }
 

@@ -25,7 +25,12 @@ struct RenderArgs {
   trt_hits           hits;      // SoA depth-0 hit record, y*W+x  (optional streams)
   trt_rendered_data* rendered;  // AoS, x*H+y                     (BEF rgen:72-73,111-112)
   unsigned long long* stats;    // [4]: primary, bounce, shadow tests, pixels (optional)
-  unsigned int*       queue;    // persistent kernel: global tile/pixel counter (zeroed per launch)
+  // persistent kernel: tile lists built by tile_classify_kernel (packed tx | ty << 16)
+  unsigned int*       queue;        // [0] = #LIVE tiles, [1] = #CLEAR tiles (zeroed per launch)
+  uint32_t*           tiles_live;   // tiles that need ray tracing
+  uint32_t*           tiles_clear;  // tiles whose every pixel misses every bounding sphere
+  uint32_t            tile_cull;    // 0: classify every tile as LIVE
+  uint32_t            vec4_ok;      // W % 4 == 0 and all first-hit streams 16-B aligned: dwordx4 clears
 };
 
 struct TraceArgs {
@@ -35,7 +40,7 @@ struct TraceArgs {
   unsigned long long* stats;
 };
 
-enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1 };
+enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1, kRenderListed = 2 };
 constexpr int kPersistentBlocksPerCU = 4;  // 256-thread blocks resident per CU (16 waves/CU)
 
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
