@@ -47,13 +47,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hits", default="tpn", choices=["tpn", "none"], help="first-hit record streams to write")
     ap.add_argument("--center", default="0,0,0", help="camera look-at point (diagnostics; default = BASELINE)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
     return ap.parse_args()
 
 
 def cpu_baseline(sc, g, pc, W, H):
-    """The oracle (a scalar C port — the reference has NO CPU path) timed on this host's cores
-    on a bounded sample of the same frame: row groups of 8 spread evenly over the image."""
+    """The oracle (a scalar C port — the reference has NO CPU path) timed on this host's cores:
+    whole frames of the same workload, OpenMP over 64-pixel blocks, until ~10-30 s of aggregate
+    CPU time have been spent (wall x threads), at most 8 frames."""
     import numpy as np
     from oracle import oracle
     from toroidal_ray_tracing_amd import abi
@@ -73,23 +73,17 @@ def cpu_baseline(sc, g, pc, W, H):
         assert rc == 0
         return time.perf_counter() - t0
 
-    # calibrate on the central 64 rows, then size the sample for ~10 s of aggregate CPU work
-    dt = run(H // 2 - 32, H // 2 + 32)
-    per_row = dt / 64
-    groups = int(min(H // 8, max(8, 10.0 / max(per_row * 8 * cores, 1e-9) / 1)))
-    groups = min(groups, H // 8)
-    step = max(1, (H // 8) // groups)
-    bands = [(8 * k, 8 * k + 8) for k in range(0, H // 8, step)]
-    t = 0.0
-    px = 0
-    for r0, r1 in bands:
-        t += run(r0, r1)
-        px += (r1 - r0) * W
+    run(0, min(H, 64))  # warm up the thread pool and the page tables
+    t, frames = 0.0, 0
+    while frames < 8 and (frames < 2 or t * cores < 15.0):
+        t += run(0, H)
+        frames += 1
+    px = frames * W * H
     return {"value": px * sc.n_tori / t, "unit": "primary ray-torus tests/s", "cores": cores,
             "kind": "port",
-            "sample": f"{len(bands)} groups of 8 rows spread evenly over the {W}x{H} frame "
-                      f"({px} pixels, {t:.2f} s wall on {cores} OpenMP threads); "
-                      "build's C restatement — the reference has no CPU path"}
+            "sample": f"{frames} full {W}x{H} frames of the same workload ({t:.2f} s wall on {cores} "
+                      f"OpenMP threads = {t * cores:.0f} s of CPU time); build's C restatement of the "
+                      "reference's GLSL — the reference has no CPU path"}
 
 
 def main():

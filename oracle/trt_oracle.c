@@ -419,14 +419,18 @@ int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* sce
   const toro_frame F = toroidal_frame(g, pc);
   uint64_t np = 0, nb = 0, ns = 0;
   (void)nthreads;
+  /* work items: blocks of 64 pixels of a row (fine enough to keep >100 threads busy on an 8-row band) */
+  const int64_t bpr = ((int64_t)W + 63) / 64, nblk = bpr * (int64_t)(row_end - row_begin);
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1) \
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads > 0 ? nthreads : 1) \
     reduction(+ : np, nb, ns)
 #endif
-  for(uint32_t y = row_begin; y < row_end; ++y)
+  for(int64_t blk = 0; blk < nblk; ++blk)
   {
+    const uint32_t y  = row_begin + (uint32_t)(blk / bpr);
+    const uint32_t xb = (uint32_t)(blk % bpr) * 64, xe = xb + 64 < W ? xb + 64 : W;
     trt_stats st = {0, 0, 0, 0};
-    for(uint32_t x = 0; x < W; ++x)
+    for(uint32_t x = xb; x < xe; ++x)
     {
       pixel_out o;
       shade_pixel(&S, g, pc, &F, W, H, camera, x, y, &o, &st);

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of render variants in ONE process (cdna guide §5.4 rule 24).
+usage: tools_ab.py [--size 4096] [--depth 5] [--rounds 7] [--frames 10] variant[:ENV=VAL,...] ..."""
+import argparse, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+from toroidal_ray_tracing_amd import abi, camera
+from toroidal_ray_tracing_amd.tracer import Tracer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=4096)
+ap.add_argument("--depth", type=int, default=5)
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--frames", type=int, default=10)
+ap.add_argument("--center", default="0,0,0")
+ap.add_argument("--scene", default="single")
+ap.add_argument("--f64", action="store_true")
+ap.add_argument("specs", nargs="+")
+a = ap.parse_args()
+W = H = a.size
+dev = torch.device("cuda:0")
+sc = camera.single_torus_scene() if a.scene == "single" else camera.nested_tori_scene()
+g = camera.globals_for((0.0, 1.5, -4.0), tuple(float(v) for v in a.center.split(",")), W, H)
+pc = camera.baseline_push(a.depth)
+tr = Tracer(0)
+if a.f64:
+    tr.set_solver(abi.TRT_SOLVE_F64)
+rgba = torch.empty(H, W, 4, device=dev)
+hits = {k: torch.empty(H * W, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
+hp = {k: v.data_ptr() for k, v in hits.items()}
+s = torch.cuda.current_stream()
+res = {spec: [] for spec in a.specs}
+def run(spec, n):
+    v, _, envs = spec.partition(":")
+    saved = {}
+    for kv in filter(None, envs.split(",")):
+        k, _, val = kv.partition("=")
+        saved[k] = os.environ.get(k); os.environ[k] = val
+    tr.set_render_variant(v)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(n):
+        tr.render_dev(sc, g, pc, W, H, rgba.data_ptr(), hit_ptrs=hp, stream=s.cuda_stream)
+    e1.record(s); torch.cuda.synchronize()
+    for k, old in saved.items():
+        if old is None: os.environ.pop(k, None)
+        else: os.environ[k] = old
+    return e0.elapsed_time(e1) / n
+for spec in a.specs:
+    run(spec, 3)
+for r in range(a.rounds):
+    for spec in a.specs:
+        res[spec].append(run(spec, a.frames))
+for spec in a.specs:
+    v = res[spec]
+    print(f"{spec:40s} median {statistics.median(v):.4f} ms  min {min(v):.4f}  max {max(v):.4f}  "
+          f"frac@median {44 * W * H / (statistics.median(v) * 1e-3) / 1e9 / 8000:.3f}")

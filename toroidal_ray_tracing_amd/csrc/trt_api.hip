@@ -34,7 +34,7 @@ struct trt_ctx {
   int           device    = 0;
   int           n_cus     = 256;
   int           precision = TRT_SOLVE_F32;
-  RenderVariant variant   = kRenderStatic;
+  RenderVariant variant   = kRenderListed;
   bool          stats_on  = false;
   std::string   err;
   hipStream_t   last_stream = nullptr;
@@ -100,6 +100,7 @@ void torus_prepare(const trt_torus& t, TorusK<Real>& k)
   k.rpol   = r * (Real)0.03125;
   k.k0     = R2 - r2;
   k.Rb2    = std::fma(s2, (Real)0.001953125, s2);
+  k.rs     = std::fma(r, (Real)0.00390625, r);
   k.fourR2 = (Real)4 * R2;
 }
 

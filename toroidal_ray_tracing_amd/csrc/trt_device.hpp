@@ -66,7 +66,8 @@ struct TorusK {   // per-torus constants of the solver
   Real r2;      // r²
   Real rpol;    // r/32: largest step the geometric polish may take
   Real k0;      // R² - r²
-  Real Rb2;     // (R+r)²·(1+2⁻⁹): squared radius of the slightly inflated bounding sphere
+  Real Rb2;     // (R+r)²·(1+2⁻⁹): squared radius of the slightly inflated bounding sphere / cylinder
+  Real rs;      // r·(1+2⁻⁸): half height of the slightly inflated bounding slab |y| <= rs
   Real fourR2;  // 4R²
 };
 
@@ -149,13 +150,39 @@ struct TorusTest {
     if(!(m <= T.Rb2))
       return false;
     const Real U  = sqrt_((T.Rb2 - m) * inv_dd);
-    const Real lo = max_(tmin - tc, -U);
+    Real lo = max_(tmin - tc, -U);
     hi = min_(tmax - tc, U);
     if(!(lo < hi))
       return false;
     const Real a     = fma_(dz_, dz_, dx_ * dx_);
     const Real b     = fma_(qz, dz_, qx * dx_);
     const Real c     = fma_(qz, qz, qx * qx);
+    // T1b: clip the window to the bounding cylinder ρ² <= Rb² and slab |y| <= rs (both slightly
+    // inflated, so the walk still starts strictly outside the torus).  The box holds only
+    // 1.5·r/(R+r) of the sphere's volume: most rays that pass the sphere but miss the torus end
+    // here without a single Newton step, and the others start next to the surface.
+    if(a > Real(0))
+    {
+      const Real disc = fma_(b, b, -(a * (c - T.Rb2)));
+      if(!(disc >= Real(0)))
+        return false;
+      const Real sq = sqrt_(disc), inv_a = Real(1) / a;
+      lo = max_(lo, (-b - sq) * inv_a);
+      hi = min_(hi, (sq - b) * inv_a);
+    }
+    else if(!(c <= T.Rb2))
+      return false;
+    if(dy_ != Real(0))
+    {
+      const Real inv_dy = Real(1) / dy_;
+      const Real u0 = (-T.rs - qy) * inv_dy, u1 = (T.rs - qy) * inv_dy;
+      lo = max_(lo, min_(u0, u1));
+      hi = min_(hi, max_(u0, u1));
+    }
+    else if(!(abs_(qy) <= T.rs))
+      return false;
+    if(!(lo < hi))
+      return false;
     const Real kappa = m + T.k0;
     A4    = dd * dd;
     P2    = fma_(-T.fourR2, a, (Real(2) * dd) * kappa);
@@ -265,8 +292,8 @@ struct TorusTest {
 
 template <class Real>
 __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
-                                                Real dz_, Real dd, Real inv_dd, Real tmin,
-                                                Real tmax, const TorusK<Real>& T, Real& t_out)
+                                                Real dz_, Real dd, Real inv_dd, Real tmin, Real tmax,
+                                                const TorusK<Real>& T, Real& t_out)
 {
   TorusTest<Real> q;
   if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))

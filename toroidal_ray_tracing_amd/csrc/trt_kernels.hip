@@ -716,8 +716,11 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
 // macro tiles.  The grid is several times larger than the number of resident blocks, so the
 // hardware workgroup dispatcher balances the (very uneven) tile costs; the clear stores of
 // blocks that finish early overlap the solve of the others.
+#ifndef TRT_LISTED_WAVES
+#define TRT_LISTED_WAVES 4
+#endif
 template <class Real>
-__global__ __launch_bounds__(256) void render_listed_kernel(const SceneK scene, const RenderArgs a)
+__global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) void render_listed_kernel(const SceneK scene, const RenderArgs a)
 {
   __shared__ SceneK S;
   stage_scene(&S, scene);
