@@ -40,7 +40,8 @@ struct trt_ctx {
   hipStream_t   last_stream = nullptr;
 
   unsigned long long* d_stats = nullptr;  // [4]
-  unsigned int*       d_queue = nullptr;  // persistent kernel work counter
+  unsigned int*       d_queue = nullptr;  // tile-list counters, two sets of 32 words (double-buffered)
+  int                 queue_parity = 0;
   uint64_t            stats_pixels = 0;
 
   // toroidal camera tables: device copy + pinned host staging + cache key
@@ -254,7 +255,8 @@ extern "C" int trt_create(int device, trt_ctx** out)
   if((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess
      || (e = hipMalloc((void**)&ctx->d_stats, 4 * sizeof(unsigned long long))) != hipSuccess
      || (e = hipMalloc((void**)&ctx->d_queue, 64 * sizeof(unsigned int))) != hipSuccess
-     || (e = hipMemset(ctx->d_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess)
+     || (e = hipMemset(ctx->d_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess
+     || (e = hipMemset(ctx->d_queue, 0, 64 * sizeof(unsigned int))) != hipSuccess)
   {
     fail(nullptr, TRT_E_HIP, "trt_create: %s", hipGetErrorString(e));
     trt_destroy(ctx);
@@ -470,11 +472,14 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     // tile culling needs tiles that are 8 contiguous image rows, and no per-pixel ray export
     a.tile_cull = (rendered == nullptr && (a.tile_parts <= 1 || a.tile_group % 8 == 0)) ? 1u : 0u;
     if(getenv("TRT_NO_TILE_CULL")) a.tile_cull = 0;
+    if(const char* e = getenv("TRT_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(e);  // timing ablations only
     uintptr_t bits = 0;
     const void* hp[8] = {a.hits.t, a.hits.px, a.hits.py, a.hits.pz, a.hits.nx, a.hits.ny, a.hits.nz, a.hits.id};
     for(const void* q : hp) bits |= (uintptr_t)q;
     a.vec4_ok = (W % 4 == 0 && (bits & 15) == 0) ? 1u : 0u;
-    TRT_HIP(ctx, hipMemsetAsync(ctx->d_queue, 0, 64 * sizeof(unsigned int), st));
+    a.queue      = ctx->d_queue + 32 * ctx->queue_parity;        // zeroed at create / by the previous frame
+    a.queue_next = ctx->d_queue + 32 * (ctx->queue_parity ^ 1);
+    if(a.n_local_rows && W) ctx->queue_parity ^= 1;  // an empty launch runs no kernel: keep the zeroed set
   }
   ctx->last_stream = st;
   TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
@@ -482,7 +487,7 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
   {
     unsigned int q[2];
     TRT_HIP(ctx, hipStreamSynchronize(st));
-    TRT_HIP(ctx, hipMemcpy(q, ctx->d_queue, sizeof q, hipMemcpyDeviceToHost));
+    TRT_HIP(ctx, hipMemcpy(q, a.queue, sizeof q, hipMemcpyDeviceToHost));
     fprintf(stderr, "[trt] tiles: live=%u clear=%u (cull=%u)\n", q[0], q[1], a.tile_cull);
   }
   return TRT_OK;

@@ -314,7 +314,7 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
   return true;
 }
 
-constexpr int kClassifyThreads = 1024;
+constexpr int kClassifyThreads = 256;
 constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8×8 tiles = 32×8 pixels
 
 // One lane per MACRO tile (32×8 pixels: one 128-B line of every first-hit stream per row).
@@ -323,13 +323,18 @@ constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8
 __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const SceneK scene, const RenderArgs a)
 {
   // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
-  // per list per 1024 macro tiles (a returning atomic on a shared word costs ≈11 ns under
+  // per list per block of macro tiles (a returning atomic on a shared word costs ≈11 ns under
   // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare)
   __shared__ uint32_t wave_cnt[2][kClassifyThreads / 64];
   __shared__ uint32_t block_base[2];
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  // The list counters are double-buffered: this frame counts in a.queue, and zeroes the set
+  // the NEXT frame will count in (no memset launch between frames; frames of one ctx are
+  // ordered by the caller, include/trt.h).
+  if(t < 2)
+    a.queue_next[t] = 0u;
   const bool     valid = t < macro_x * tiles_y;
   const uint32_t mx = t % macro_x, ty = t / macro_x;
   const uint32_t tx0 = mx * kMacroTiles;
@@ -731,22 +736,33 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
 
-  for(uint32_t e = g_wave; e < n_live; e += n_waves)
+  // Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k prefetches the wave's k-th
+  // entry of the current batch of 64 (one gather load per list per batch) and entries are
+  // broadcast with v_readlane, so no load — and hence no s_waitcnt vmcnt that would drain the
+  // output stores — sits between the tiles.  Clear macro tiles (pure stores) are interleaved
+  // with the traced tiles: the HBM-bound half of the frame drains behind the VALU-bound half.
+  const uint32_t my_live  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;
+  const uint32_t my_clear = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
+  const float4   clear_c  = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f,
+                                        a.pc.clearColor[2] * 0.8f, 1.0f);
+  const uint32_t n_iter = my_live > my_clear ? my_live : my_clear;
+  uint32_t live_cache = 0, clear_cache = 0;
+  for(uint32_t i = 0; i < n_iter; ++i)
   {
-    const uint32_t packed = __builtin_amdgcn_readfirstlane(a.tiles_live[e]);
-    const uint32_t x = (packed & 0xffffu) * 8 + (lane & 7), ly = (packed >> 16) * 8 + (lane >> 3);
-    if(x < a.W && ly < a.n_local_rows)
-      trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
-  }
-  const float4 clear_c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f,
-                                     a.pc.clearColor[2] * 0.8f, 1.0f);
-  for(uint32_t base = g_wave; base < n_clear; base += 64u * n_waves)
-  {
-    // lane k prefetches the wave's k-th entry of this batch: no load between the stores
-    const uint32_t mine = base + lane * n_waves < n_clear ? a.tiles_clear[base + (size_t)lane * n_waves] : 0u;
-    const uint32_t cnt  = (n_clear - base + n_waves - 1) / n_waves;
-    for(uint32_t k = 0; k < (cnt < 64u ? cnt : 64u); ++k)
-      n_primary += clear_macro(a, __builtin_amdgcn_readlane(mine, k), lane, clear_c) * (uint32_t)S.n_tori;
+    if((i & 63u) == 0)
+    {
+      live_cache  = i + lane < my_live ? a.tiles_live[g_wave + (size_t)(i + lane) * n_waves] : 0u;
+      clear_cache = i + lane < my_clear ? a.tiles_clear[g_wave + (size_t)(i + lane) * n_waves] : 0u;
+    }
+    if(i < my_clear && !(a.debug_skip & 1u))
+      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane, clear_c) * (uint32_t)S.n_tori;
+    if(i < my_live && !(a.debug_skip & 2u))
+    {
+      const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
+      const uint32_t x = (packed & 0xffffu) * 8 + (lane & 7), ly = (packed >> 16) * 8 + (lane >> 3);
+      if(x < a.W && ly < a.n_local_rows)
+        trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+    }
   }
   if(a.stats)
   {
