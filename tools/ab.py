@@ -2,7 +2,7 @@
 """Interleaved A/B timing of render variants in ONE process (cdna guide §5.4 rule 24).
 usage: tools_ab.py [--size 4096] [--depth 5] [--rounds 7] [--frames 10] variant[:ENV=VAL,...] ..."""
 import argparse, os, statistics, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from toroidal_ray_tracing_amd import abi, camera
 from toroidal_ray_tracing_amd.tracer import Tracer
