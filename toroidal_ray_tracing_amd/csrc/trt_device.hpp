@@ -264,6 +264,42 @@ struct TorusTest {
     return !done;
   }
 
+  // step() for a lane that is iterating (mode FWD or BWD): the same arithmetic and the same
+  // decisions, minus every piece-transition term.  The solve loops take this path on the
+  // trips in which no running lane of the wave sits at a piece end (wave-uniform choice).
+  __device__ __forceinline__ bool step_iter()
+  {
+    const Real u  = xe;
+    const Real e1 = fma_(A4 * u, u, P2);
+    const Real e2 = fma_(e1, u, Q1);
+    const Real fe = fma_(e2, u, S0);
+    const Real g1 = fma_((Real(4) * A4) * u, u, Real(2) * P2);
+    const Real de = fma_(g1, u, Q1);
+    const bool fwd  = mode == M_FWD;
+    const bool flip = fe == Real(0) || ((fe > Real(0)) ? 1 : -1) != sref;
+    const int  it2  = it + 1;
+    const bool cap  = it2 == kNewtonCap;
+    const Real sdx  = sigma > 0 ? de : -de;
+    const Real xn   = u - fe / de;
+    // forward: flip -> hit, cap -> hit, slope/range -> END, converged -> hit
+    // backward: cap -> hit, flip/slope -> hit, left of A -> hit(A), converged -> hit
+    const bool f_no   = fwd && !flip && !cap && (!(sdx < Real(0)) || !(xn < B));
+    const bool b_stop = flip || !(sdx > Real(0));
+    const bool b_hitA = !fwd && !cap && !b_stop && !(xn > A);
+    const bool hit_x  = fwd ? (flip || cap || (!f_no && xn == u))
+                            : (cap || b_stop || (!b_hitA && xn == u));
+    const bool done   = hit_x || b_hitA;
+    found = done;
+    root  = b_hitA ? A : u;
+    it    = it2;
+    xe    = f_no ? B : (done ? u : xn);
+    mode  = done ? M_DONE : (f_no ? M_END : mode);
+    return !done;
+  }
+
+  // true when step_iter() applies to this lane
+  __device__ __forceinline__ bool iterating() const { return mode == M_FWD || mode == M_BWD; }
+
   // T2b: one Newton step on g(u) = (ρ-R)² + py² - r², whose rounding error scales with r²
   // instead of R⁴ (a step above r/32 — grazing, g' ≈ 0 — is discarded); then t = u + tc and
   // the open-interval test of the closest-hit query.
@@ -298,7 +334,15 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
   TorusTest<Real> q;
   if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))
     return false;
-  while(q.step()) {}
+  // per trip: the cheap iteration-only step when every running lane of the wave is iterating
+  bool run = true;
+  while(run)
+  {
+    if(__any(!q.iterating()))
+      run = q.step();
+    else
+      run = q.step_iter();
+  }
   return q.finish(dx_, dy_, dz_, tmin, tmax, T, t_out);
 }
 

@@ -272,7 +272,9 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
 // line is 1-Lipschitz in the origin and |C-o|-Lipschitz in the direction angle, hence
 //     dist >= dl - Δo - (L + Δo)·θ,   dl = dist(C, centre line), L = |C - oc|,
 // and the tile is clear when that exceeds the sphere radius by 1.6 % + 1e-5·(L+1) — three
-// orders of magnitude above the FP32 rounding of the per-pixel test.  Anything doubtful
+// orders of magnitude above the FP32 rounding of the per-pixel test.  A second test does the
+// same for the bounding box (cylinder ∩ slab) TorusTest::setup() clips to, which removes the
+// caps of the sphere's silhouette and everything behind the camera.  Anything doubtful
 // (NaN, wide tiles, origin near the sphere) is LIVE.  Tiles are appended to two compact lists
 // (one wave-aggregated atomic per list per wave); order within the lists is irrelevant.
 __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs& a, uint32_t x0, uint32_t ty, uint32_t width)
@@ -308,8 +310,44 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
     const float L2 = dot3(v, v), s = dot3(v, dc);
     const float L  = sqrt_(L2), dl = sqrt_(max_(L2 - s * s, 0.0f));
     const float rb = sqrt_(S.k32[i].Rb2);
-    if(!(dl - dO - (L + dO) * theta > rb * 1.015625f + 1e-5f * (L + 1.0f)))
-      return false;
+    // (1) every line of the bundle misses the bounding sphere
+    if(dl - dO - (L + dO) * theta > rb * 1.015625f + 1e-5f * (L + 1.0f))
+      continue;
+    // (2) the centre ray misses the bounding box (cylinder ∩ slab, the solid TorusTest::setup
+    //     clips to) inflated by delta, the largest distance between a point of any ray of the
+    //     bundle and the centre ray's point at the same parameter, over the parameters at which
+    //     the sphere can be met (t <= L + rb): delta = Δo + (L + rb)·θ
+    const float delta = 1.02f * (dO + (L + rb) * theta) + 1e-5f * (L + 1.0f);
+    const float Rc = rb * 1.015625f + delta, hs = S.k32[i].rs * 1.015625f + delta;
+    const float ex = -v.x, ey = -v.y, ez = -v.z;
+    float t_lo = 0.0f, t_hi = L + rb + delta;   // forward half-line only, inside the sphere's reach
+    const float ca = fma_(dc.z, dc.z, dc.x * dc.x), cb = fma_(ez, dc.z, ex * dc.x), cc = fma_(ez, ez, ex * ex);
+    bool miss = false;
+    if(ca > 1e-12f)
+    {
+      const float disc = fma_(cb, cb, -(ca * (cc - Rc * Rc)));
+      if(disc < 0.0f) miss = true;
+      else
+      {
+        const float sq = sqrt_(disc), ia = 1.0f / ca;
+        t_lo = max_(t_lo, (-cb - sq) * ia - delta);
+        t_hi = min_(t_hi, (sq - cb) * ia + delta);
+      }
+    }
+    else if(cc > Rc * Rc) miss = true;
+    if(!miss)
+    {
+      if(abs_(dc.y) > 1e-6f)
+      {
+        const float iy = 1.0f / dc.y, u0 = (-hs - ey) * iy, u1 = (hs - ey) * iy;
+        t_lo = max_(t_lo, min_(u0, u1) - delta);
+        t_hi = min_(t_hi, max_(u0, u1) + delta);
+      }
+      else if(abs_(ey) > hs) miss = true;
+    }
+    if(miss || t_lo > t_hi)
+      continue;
+    return false;  // this torus may be hit by some ray of the tile (NaNs land here too)
   }
   return true;
 }
@@ -320,20 +358,30 @@ constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8
 // One lane per MACRO tile (32×8 pixels: one 128-B line of every first-hit stream per row).
 // A clear macro tile becomes ONE entry of the CLEAR list (written later with full-line
 // dwordx4 stores); any other macro tile contributes its 8×8 tiles to the LIVE list.
+// The LIVE list can be filled from both ends (a.tile_sort, off by default): tiles whose centre
+// ray hits a torus ("heavy") from the front, the others from the back, so that the waves —
+// which walk the list front to back — finish with cheap tiles.  Measured on MI355X this
+// longest-first order LOSES (render +10 %, classify 8 → 26 µs): kept only as an experiment.
+__device__ __forceinline__ uint32_t live_slot(const RenderArgs& a, uint32_t e, uint32_t n_heavy)
+{
+  return e < n_heavy ? e : a.tiles_cap - 1u - (e - n_heavy);
+}
+
 __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const SceneK scene, const RenderArgs a)
 {
   // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
   // per list per block of macro tiles (a returning atomic on a shared word costs ≈11 ns under
-  // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare)
-  __shared__ uint32_t wave_cnt[2][kClassifyThreads / 64];
-  __shared__ uint32_t block_base[2];
+  // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare).  Lists: 0 = LIVE heavy,
+  // 1 = CLEAR, 2 = LIVE light.
+  __shared__ uint32_t wave_cnt[3][kClassifyThreads / 64];
+  __shared__ uint32_t block_base[3];
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   // The list counters are double-buffered: this frame counts in a.queue, and zeroes the set
   // the NEXT frame will count in (no memset launch between frames; frames of one ctx are
   // ordered by the caller, include/trt.h).
-  if(t < 2)
+  if(t < 3)
     a.queue_next[t] = 0u;
   const bool     valid = t < macro_x * tiles_y;
   const uint32_t mx = t % macro_x, ty = t / macro_x;
@@ -343,19 +391,36 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   const uint32_t nlive = clear ? 0u : ntile;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  // wave-level exclusive prefix of nlive (0..4) and of clear (0/1)
-  uint32_t live_pre = nlive, clear_pre = clear ? 1u : 0u;
+  // heaviness of each live tile: does its centre ray hit anything?
+  uint32_t heavy_mask = 0;
+  if(a.tile_sort)
+    for(uint32_t j = 0; j < nlive; ++j)
+    {
+      const uint32_t x = min((tx0 + j) * 8 + 4, a.W - 1), ly = min(ty * 8 + 4, a.n_local_rows - 1);
+      v3 o, d;
+      raygen(a.g, a.toro, a.W, a.H, a.camera, x, image_row(a, ly), o, d);
+      float    th;
+      uint32_t dummy = 0;
+      if(closest_hit<float>(scene, o, d, kTMin, kTMax, th, dummy) >= 0)
+        heavy_mask |= 1u << j;
+    }
+  const uint32_t nheavy = (uint32_t)__popc(heavy_mask), nlight = nlive - nheavy;
+
+  // wave-level exclusive prefixes of the three counts
+  uint32_t pre[3] = {nheavy, clear ? 1u : 0u, nlight};
 #pragma unroll
   for(int off = 1; off < 64; off <<= 1)
-  {
-    const uint32_t l = __shfl_up(live_pre, off, 64), c = __shfl_up(clear_pre, off, 64);
-    if(lane >= (uint32_t)off) { live_pre += l; clear_pre += c; }
-  }
-  if(lane == 63) { wave_cnt[0][wave] = live_pre; wave_cnt[1][wave] = clear_pre; }
-  live_pre -= nlive;
-  clear_pre -= clear ? 1u : 0u;
+#pragma unroll
+    for(int k = 0; k < 3; ++k)
+    {
+      const uint32_t v = __shfl_up(pre[k], off, 64);
+      if(lane >= (uint32_t)off) pre[k] += v;
+    }
+  if(lane == 63)
+    for(int k = 0; k < 3; ++k) wave_cnt[k][wave] = pre[k];
+  pre[0] -= nheavy; pre[1] -= clear ? 1u : 0u; pre[2] -= nlight;
   __syncthreads();
-  if(threadIdx.x < 2)
+  if(threadIdx.x < 3)
   {
     uint32_t sum = 0;
     for(uint32_t w = 0; w < kClassifyThreads / 64; ++w)
@@ -368,9 +433,14 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   }
   __syncthreads();
   if(clear)
-    a.tiles_clear[block_base[1] + wave_cnt[1][wave] + clear_pre] = tx0 | (ty << 16);
+    a.tiles_clear[block_base[1] + wave_cnt[1][wave] + pre[1]] = tx0 | (ty << 16);
+  uint32_t ih = block_base[0] + wave_cnt[0][wave] + pre[0], il = block_base[2] + wave_cnt[2][wave] + pre[2];
   for(uint32_t j = 0; j < nlive; ++j)
-    a.tiles_live[block_base[0] + wave_cnt[0][wave] + live_pre + j] = (tx0 + j) | (ty << 16);
+  {
+    const uint32_t packed = (tx0 + j) | (ty << 16);
+    if(heavy_mask & (1u << j)) a.tiles_live[ih++] = packed;
+    else a.tiles_live[a.tiles_cap - 1u - il++] = packed;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -462,7 +532,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
   const int      n_tori  = S.n_tori;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(a.queue[0]);
+  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(a.queue[0]);
+  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(a.queue[2]);
   const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
   const float4   clear_c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f,
                                        a.pc.clearColor[2] * 0.8f, 1.0f);  // rmiss:37, rgen:76 (×1 + 0), rgen:87
@@ -474,7 +545,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
   const uint32_t my_live_n  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;   // entries owned
   const uint32_t my_clear_n = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
   uint32_t k_live = 0, k_clear = 0;  // next owned entry (wave-uniform)
-  uint32_t live_cache  = lane < my_live_n ? a.tiles_live[g_wave + (size_t)lane * n_waves] : 0u;
+  uint32_t live_cache  = lane < my_live_n ? a.tiles_live[live_slot(a, g_wave + lane * n_waves, n_heavy)] : 0u;
   uint32_t clear_cache = lane < my_clear_n ? a.tiles_clear[g_wave + (size_t)lane * n_waves] : 0u;
   bool     exhausted = my_live_n == 0;
   uint32_t cur = __builtin_amdgcn_readlane(live_cache, 0);
@@ -653,7 +724,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
           if(!exhausted)
           {
             if((k_live & 63u) == 0)
-              live_cache = k_live + lane < my_live_n ? a.tiles_live[g_wave + (size_t)(k_live + lane) * n_waves] : 0u;
+              live_cache = k_live + lane < my_live_n ? a.tiles_live[live_slot(a, g_wave + (k_live + lane) * n_waves, n_heavy)] : 0u;
             cur = __builtin_amdgcn_readlane(live_cache, k_live & 63u);
           }
         }
@@ -682,9 +753,10 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
     // ------------------------------ (B) solve ---------------------------------------------
     while(__any(inflight))
     {
+      const bool slow = __any(inflight && !tst.iterating());
       if(inflight)
       {
-        inflight   = tst.step();
+        inflight   = slow ? tst.step() : tst.step_iter();
         unconsumed = !inflight;
       }
     }
@@ -732,7 +804,8 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   const uint32_t lane    = threadIdx.x & 63;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(a.queue[0]);
+  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(a.queue[0]);
+  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(a.queue[2]);
   const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
 
@@ -751,7 +824,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   {
     if((i & 63u) == 0)
     {
-      live_cache  = i + lane < my_live ? a.tiles_live[g_wave + (size_t)(i + lane) * n_waves] : 0u;
+      live_cache  = i + lane < my_live ? a.tiles_live[live_slot(a, g_wave + (i + lane) * n_waves, n_heavy)] : 0u;
       clear_cache = i + lane < my_clear ? a.tiles_clear[g_wave + (size_t)(i + lane) * n_waves] : 0u;
     }
     if(i < my_clear && !(a.debug_skip & 1u))

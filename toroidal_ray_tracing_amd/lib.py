@@ -10,7 +10,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrt.so")
+LIB_PATH = os.environ.get("TRT_LIB") or os.path.join(_HERE, "libtrt.so")  # TRT_LIB: A/B builds (tools/)
 
 #: every entry point ``include/trt.h`` declares: name -> (restype, argtypes)
 SYMBOLS = {
