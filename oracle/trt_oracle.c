@@ -221,7 +221,8 @@ static v3 compute_specular(const trt_material* m, v3 viewDir, v3 L, v3 N)
   const float kEnergy    = (2.0f + kShininess) / (2.0f * kPi);                 /* :42 */
   const v3    V          = normalize3(neg3(viewDir));                          /* :43 */
   const v3    R          = reflect3(neg3(L), N);                               /* :44 */
-  const float s          = kEnergy * powf(fmaxf(dot3(V, R), 0.0f), kShininess); /* :45 */
+  /* :45 — GLSL defines pow(x,y) = exp2(y*log2(x)) (GLSL 4.60 §8.2); restated that way */
+  const float s          = kEnergy * exp2f(kShininess * log2f(fmaxf(dot3(V, R), 0.0f)));
   v3 r = {m->specular[0] * s, m->specular[1] * s, m->specular[2] * s};         /* :47 */
   return r;
 }

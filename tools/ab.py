@@ -15,6 +15,7 @@ ap.add_argument("--frames", type=int, default=10)
 ap.add_argument("--center", default="0,0,0")
 ap.add_argument("--scene", default="single")
 ap.add_argument("--f64", action="store_true")
+ap.add_argument("--hits", default="tpn")
 ap.add_argument("specs", nargs="+")
 a = ap.parse_args()
 W = H = a.size
@@ -27,7 +28,7 @@ if a.f64:
     tr.set_solver(abi.TRT_SOLVE_F64)
 rgba = torch.empty(H, W, 4, device=dev)
 hits = {k: torch.empty(H * W, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
-hp = {k: v.data_ptr() for k, v in hits.items()}
+hp = {k: v.data_ptr() for k, v in hits.items()} if a.hits == "tpn" else None
 s = torch.cuda.current_stream()
 res = {spec: [] for spec in a.specs}
 def run(spec, n):

@@ -38,6 +38,8 @@ struct trt_ctx {
   bool          stats_on  = false;
   std::string   err;
   hipStream_t   last_stream = nullptr;
+  hipStream_t   side_stream = nullptr;  // experiments only (TRT_LISTED_SPLIT)
+  hipEvent_t    ev_fork = nullptr, ev_join = nullptr;
 
   unsigned long long* d_stats = nullptr;  // [4]
   unsigned int*       d_queue = nullptr;  // tile-list counters, two sets of 32 words (double-buffered)
@@ -484,7 +486,14 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     if(a.n_local_rows && W) ctx->queue_parity ^= 1;  // an empty launch runs no kernel: keep the zeroed set
   }
   ctx->last_stream = st;
-  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
+  if(getenv("TRT_LISTED_SPLIT") && !ctx->side_stream)
+  {
+    TRT_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    TRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    TRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st, getenv("TRT_LISTED_SPLIT") ? ctx->side_stream : nullptr,
+                             ctx->ev_fork, ctx->ev_join));
   if(ctx->variant != kRenderStatic && getenv("TRT_DEBUG_TILES"))
   {
     unsigned int q[3];

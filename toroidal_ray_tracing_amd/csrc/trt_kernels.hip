@@ -117,6 +117,18 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v)
     atomicAdd(dst, (unsigned long long)v);
 }
 
+// Retire every outstanding load of this wave, then hide the given registers from hipcc's
+// s_waitcnt bookkeeping.  Without this, a value loaded once per batch and read in a loop (the
+// per-lane tile-list caches) gets an `s_waitcnt vmcnt(0)` in front of EVERY read — and since
+// stores share the counter, each of those waits drains the wave's whole stream of output
+// stores (measured: the clear tiles then serialise with the traced tiles instead of
+// draining behind them).
+__device__ __forceinline__ void settle_loads(uint32_t& a, uint32_t& b)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" : "+v"(a), "+v"(b));
+}
+
 // Stage the launch arguments into LDS next to the scene.  Kept in the kernel-argument segment
 // they would be pinned in ~150 SGPRs for the whole persistent loop (hipcc loads kernargs once
 // and never rematerialises them), and the spills cost a dozen v_readlane per output store.
@@ -475,8 +487,10 @@ constexpr uint32_t kMinBatch = 24;
 // writes 8 full 128-B lines.  rgba takes 4 dwordx4 per lane, instruction j writing pixels
 // 8j + q: again 8 full lines per instruction.  (Narrow stores are what bounds a streaming
 // writer on this chip: a dword store of 8×32-B row pieces is issue-limited to ≈3 B/clk/CU.)
-__device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t packed, uint32_t lane, float4 c)
+__device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t packed, uint32_t lane)
 {
+  // (clearColor·0.8, 1): rmiss:37 → rgen:76 with attenuation 1 and hitValue 0 → rgen:87
+  const float4 c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, 1.0f);
   const uint32_t x0 = (packed & 0xffffu) * 8, ly = (packed >> 16) * 8 + (lane >> 3), q = lane & 7;
   if(ly >= a.n_local_rows)
     return 0;
@@ -535,8 +549,6 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
   const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(a.queue[0]);
   const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(a.queue[2]);
   const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
-  const float4   clear_c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f,
-                                       a.pc.clearColor[2] * 0.8f, 1.0f);  // rmiss:37, rgen:76 (×1 + 0), rgen:87
 
   // Queue state.  Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k caches the
   // wave's k-th entry of the current batch of 64 (one gather load per 64 tiles) and entries
@@ -547,6 +559,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
   uint32_t k_live = 0, k_clear = 0;  // next owned entry (wave-uniform)
   uint32_t live_cache  = lane < my_live_n ? a.tiles_live[live_slot(a, g_wave + lane * n_waves, n_heavy)] : 0u;
   uint32_t clear_cache = lane < my_clear_n ? a.tiles_clear[g_wave + (size_t)lane * n_waves] : 0u;
+  settle_loads(live_cache, clear_cache);
   bool     exhausted = my_live_n == 0;
   uint32_t cur = __builtin_amdgcn_readlane(live_cache, 0);
   uint32_t next_in_tile = 0;  // pixels of the current tile handed out
@@ -582,9 +595,12 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
     while(k_clear < my_clear_n)
     {
       if((k_clear & 63u) == 0 && k_clear)
+      {
         clear_cache = k_clear + lane < my_clear_n ? a.tiles_clear[g_wave + (size_t)(k_clear + lane) * n_waves] : 0u;
+        settle_loads(live_cache, clear_cache);
+      }
       const uint32_t packed = __builtin_amdgcn_readlane(clear_cache, k_clear & 63u);
-      n_primary += clear_macro(a, packed, lane, clear_c) * (uint32_t)n_tori;
+      n_primary += clear_macro(a, packed, lane) * (uint32_t)n_tori;
       ++k_clear;
       if(!(exhausted && !__any(inflight || kind != K_NONE)))
         break;
@@ -724,7 +740,10 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
           if(!exhausted)
           {
             if((k_live & 63u) == 0)
+            {
               live_cache = k_live + lane < my_live_n ? a.tiles_live[live_slot(a, g_wave + (k_live + lane) * n_waves, n_heavy)] : 0u;
+              settle_loads(live_cache, clear_cache);
+            }
             cur = __builtin_amdgcn_readlane(live_cache, k_live & 63u);
           }
         }
@@ -797,10 +816,13 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
 #define TRT_LISTED_WAVES 4
 #endif
 template <class Real>
-__global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) void render_listed_kernel(const SceneK scene, const RenderArgs a)
+__global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
 {
-  __shared__ SceneK S;
+  __shared__ SceneK     S;
+  __shared__ RenderArgs A_lds;
+  stage_args(&A_lds, a_arg);
   stage_scene(&S, scene);
+  const RenderArgs& a = A_lds;
   const uint32_t lane    = threadIdx.x & 63;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -816,8 +838,6 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   // with the traced tiles: the HBM-bound half of the frame drains behind the VALU-bound half.
   const uint32_t my_live  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;
   const uint32_t my_clear = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
-  const float4   clear_c  = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f,
-                                        a.pc.clearColor[2] * 0.8f, 1.0f);
   const uint32_t n_iter = my_live > my_clear ? my_live : my_clear;
   uint32_t live_cache = 0, clear_cache = 0;
   for(uint32_t i = 0; i < n_iter; ++i)
@@ -826,9 +846,10 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
     {
       live_cache  = i + lane < my_live ? a.tiles_live[live_slot(a, g_wave + (i + lane) * n_waves, n_heavy)] : 0u;
       clear_cache = i + lane < my_clear ? a.tiles_clear[g_wave + (size_t)(i + lane) * n_waves] : 0u;
+      settle_loads(live_cache, clear_cache);
     }
     if(i < my_clear && !(a.debug_skip & 1u))
-      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane, clear_c) * (uint32_t)S.n_tori;
+      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane) * (uint32_t)S.n_tori;
     if(i < my_live && !(a.debug_skip & 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
@@ -862,7 +883,7 @@ hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t str
 }
 
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
-                         hipStream_t stream)
+                         hipStream_t stream, hipStream_t side_stream, hipEvent_t ev_fork, hipEvent_t ev_join)
 {
   if(a.n_local_rows == 0 || a.W == 0)
     return hipSuccess;
@@ -880,11 +901,29 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
     {
       uint64_t lcap = (uint64_t)n_cus * 32;  // oversubscribed: the dispatcher balances the tile costs
       if(const char* e = getenv("TRT_LISTED_BLOCKS")) lcap = (uint64_t)atoll(e);
-      const uint32_t lgrid = (uint32_t)((tiles + 3) / 4 < lcap ? (tiles + 3) / 4 : lcap);
+      uint32_t bthreads = 256;
+      if(const char* e = getenv("TRT_LISTED_THREADS")) bthreads = (uint32_t)atoi(e);
+      const uint32_t wpb = bthreads / 64;
+      const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
+      if(side_stream && !scene.f64)
+      {
+        // experiment (TRT_LISTED_SPLIT): traced tiles on the caller's stream, clear tiles on a side
+        // stream, forked/joined with events — lets the hardware overlap the two kernels
+        RenderArgs al = a, ac = a;
+        al.debug_skip |= 1u;   // live only
+        ac.debug_skip |= 2u;   // clear only
+        hipEventRecord(ev_fork, stream);
+        hipStreamWaitEvent(side_stream, ev_fork, 0);
+        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid), dim3(bthreads), 0, stream, scene, al);
+        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid / 4 ? lgrid / 4 : 1), dim3(bthreads), 0, side_stream, scene, ac);
+        hipEventRecord(ev_join, side_stream);
+        hipStreamWaitEvent(stream, ev_join, 0);
+        return hipGetLastError();
+      }
       if(scene.f64)
-        hipLaunchKernelGGL(render_listed_kernel<double>, dim3(lgrid), dim3(256), 0, stream, scene, a);
+        hipLaunchKernelGGL(render_listed_kernel<double>, dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
       else
-        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid), dim3(256), 0, stream, scene, a);
+        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
       return hipGetLastError();
     }
     const uint32_t grid = (uint32_t)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);

@@ -49,6 +49,7 @@ constexpr int kPersistentBlocksPerCU = 4;  // 256-thread blocks resident per CU 
 
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
-                         hipStream_t stream);
+                         hipStream_t stream, hipStream_t side_stream = nullptr, hipEvent_t ev_fork = nullptr,
+                         hipEvent_t ev_join = nullptr);
 
 }  // namespace trt
