@@ -38,8 +38,6 @@ struct trt_ctx {
   bool          stats_on  = false;
   std::string   err;
   hipStream_t   last_stream = nullptr;
-  hipStream_t   side_stream = nullptr;  // experiments only (TRT_LISTED_SPLIT)
-  hipEvent_t    ev_fork = nullptr, ev_join = nullptr;
 
   unsigned long long* d_stats = nullptr;  // [4]
   unsigned int*       d_queue = nullptr;  // tile-list counters, two sets of 32 words (double-buffered)
@@ -474,6 +472,8 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     a.tiles_cap   = (uint32_t)n_tiles;
     // tile culling needs tiles that are 8 contiguous image rows, and no per-pixel ray export
     a.tile_cull = (rendered == nullptr && (a.tile_parts <= 1 || a.tile_group % 8 == 0)) ? 1u : 0u;
+    a.min_batch = 24;
+    if(const char* e = getenv("TRT_MIN_BATCH")) a.min_batch = (uint32_t)atoi(e);
     if(getenv("TRT_NO_TILE_CULL")) a.tile_cull = 0;
     a.tile_sort = (a.tile_cull && getenv("TRT_TILE_SORT")) ? 1u : 0u;
     if(const char* e = getenv("TRT_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(e);  // timing ablations only
@@ -486,14 +486,7 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     if(a.n_local_rows && W) ctx->queue_parity ^= 1;  // an empty launch runs no kernel: keep the zeroed set
   }
   ctx->last_stream = st;
-  if(getenv("TRT_LISTED_SPLIT") && !ctx->side_stream)
-  {
-    TRT_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    TRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    TRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-  }
-  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st, getenv("TRT_LISTED_SPLIT") ? ctx->side_stream : nullptr,
-                             ctx->ev_fork, ctx->ev_join));
+  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
   if(ctx->variant != kRenderStatic && getenv("TRT_DEBUG_TILES"))
   {
     unsigned int q[3];

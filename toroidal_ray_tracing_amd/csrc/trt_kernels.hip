@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
 //   (A) advances the lanes: finished queries run their shader stage (miss / closest-hit /
 //       shadow-miss) and spawn the next query or finish the pixel; idle lanes are compacted
 //       with a ballot and refilled from the wave's LIVE tiles; tests culled by the bounding
-//       sphere are skipped at once.  A round of (A) runs only for >= kMinBatch lanes (or
+//       sphere are skipped at once.  A round of (A) runs only for >= min_batch lanes (or
 //       when nothing is in flight), so the shader/refill code never runs for a few stragglers
 //       while the other lanes wait;
 //   (B) runs the solve loop — every lane evaluates (f, f') of ITS test, whatever pixel,
@@ -479,7 +479,6 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
 // saturates at ≈88 dequeues/µs, MI355X_MICROARCH.md "dequeue"), and since the LIVE list is
 // compact every wave gets the same number of non-trivial tiles.
 enum : int { K_NONE = 0, K_CLOSEST = 1, K_SHADOW = 2 };
-constexpr uint32_t kMinBatch = 24;
 
 // Writes the constant miss record of one CLEAR macro tile (32×8 pixels) and returns the number
 // of image pixels this lane wrote.  Lane l = (row r = l >> 3, q = l & 7).  Each first-hit
@@ -534,7 +533,7 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
 }
 
 template <class Real>
-__global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK scene, const RenderArgs a_arg)
+__global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persistent_kernel(const SceneK scene, const RenderArgs a_arg)
 {
   __shared__ SceneK     S;
   __shared__ RenderArgs A_lds;
@@ -611,7 +610,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(const SceneK sce
     {
       const bool needs = !inflight && !(kind == K_NONE && exhausted);
       const uint32_t n_needs = (uint32_t)__popcll(__ballot(needs));
-      if(n_needs == 0 || (n_needs < kMinBatch && __any(inflight)))
+      if(n_needs == 0 || (n_needs < a.min_batch && __any(inflight)))
         break;
 
       // A1: shader stages of finished queries
@@ -883,7 +882,7 @@ hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t str
 }
 
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
-                         hipStream_t stream, hipStream_t side_stream, hipEvent_t ev_fork, hipEvent_t ev_join)
+                         hipStream_t stream)
 {
   if(a.n_local_rows == 0 || a.W == 0)
     return hipSuccess;
@@ -905,21 +904,6 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       if(const char* e = getenv("TRT_LISTED_THREADS")) bthreads = (uint32_t)atoi(e);
       const uint32_t wpb = bthreads / 64;
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
-      if(side_stream && !scene.f64)
-      {
-        // experiment (TRT_LISTED_SPLIT): traced tiles on the caller's stream, clear tiles on a side
-        // stream, forked/joined with events — lets the hardware overlap the two kernels
-        RenderArgs al = a, ac = a;
-        al.debug_skip |= 1u;   // live only
-        ac.debug_skip |= 2u;   // clear only
-        hipEventRecord(ev_fork, stream);
-        hipStreamWaitEvent(side_stream, ev_fork, 0);
-        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid), dim3(bthreads), 0, stream, scene, al);
-        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid / 4 ? lgrid / 4 : 1), dim3(bthreads), 0, side_stream, scene, ac);
-        hipEventRecord(ev_join, side_stream);
-        hipStreamWaitEvent(stream, ev_join, 0);
-        return hipGetLastError();
-      }
       if(scene.f64)
         hipLaunchKernelGGL(render_listed_kernel<double>, dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
       else

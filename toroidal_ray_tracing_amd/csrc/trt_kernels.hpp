@@ -31,6 +31,7 @@ struct RenderArgs {
   unsigned int*       queue_next;   // the counter set of the next frame, zeroed by this one
   uint32_t*           tiles_live;   // tiles that need ray tracing
   uint32_t*           tiles_clear;  // tiles whose every pixel misses every bounding sphere
+  uint32_t            min_batch;    // persistent kernel: lanes needed to run a shader/refill round (default 24)
   uint32_t            tile_cull;    // 0: classify every tile as LIVE
   uint32_t            tile_sort;    // 1: heavy tiles first (experiment, TRT_TILE_SORT)
   uint32_t            debug_skip;   // diagnostics (TRT_DEBUG_SKIP): 1 = skip clear tiles, 2 = skip traced tiles
@@ -45,11 +46,10 @@ struct TraceArgs {
 };
 
 enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1, kRenderListed = 2 };
-constexpr int kPersistentBlocksPerCU = 4;  // 256-thread blocks resident per CU (16 waves/CU)
+constexpr int kPersistentBlocksPerCU = 16;  // 4× the resident 4 blocks/CU: the dispatcher evens out the tile costs
 
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
-                         hipStream_t stream, hipStream_t side_stream = nullptr, hipEvent_t ev_fork = nullptr,
-                         hipEvent_t ev_join = nullptr);
+                         hipStream_t stream);
 
 }  // namespace trt
