@@ -124,6 +124,7 @@ def main():
     # one counted pass (untimed): how many ray–torus tests one frame executes
     tr.enable_stats(True)
     step()
+    frame.finish()
     torch.cuda.synchronize()
     st = tr.stats()
     tr.enable_stats(False)
@@ -137,6 +138,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    frame.finish()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -145,6 +147,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(evs[k])
+    frame.finish()   # N > 1: the last frames' all-gathers are part of the K steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -1,7 +1,8 @@
 """Multi-rank path on CPU (gloo, world_size 2): the row-group tiling, the all-gather and the
 de-interleave reproduce the single-rank frame.  The per-rank renders come from the CPU
-oracle here (there is no GPU in this container); on the GPU box the same TiledFrame logic
-runs over RCCL (tests/test_gpu_parity.py::test_tiled_render_matches_full checks the
+oracle here (there is no GPU in this container) through a stand-in tracer, so the REAL
+``TiledFrame`` (pipelined all-gather, retire, finish) is what runs; on the GPU box the same
+class runs over RCCL (tests/test_gpu_parity.py::test_tiled_render_matches_full checks the
 kernels' tiling against full-frame renders on one GPU)."""
 import os
 import socket
@@ -49,28 +50,53 @@ def _free_port():
     return p
 
 
+class _OracleTracer:
+    """Stand-in for tracer.Tracer on CPU: the same render_tiled_dev signature, pixels from the
+    CPU oracle written straight into the (CPU) buffer whose address TiledFrame passes."""
+
+    def __init__(self):
+        from oracle import oracle
+        self.oracle = oracle
+
+    def tiling_rows(self, tiling, H):
+        return len(trtd.owned_rows(H, tiling.group_rows, tiling.n_parts, tiling.part))
+
+    def render_tiled_dev(self, scene, g, pc, W, H, tiling, rgba_ptr, camera=0, hit_ptrs=None, stream=0):
+        import ctypes
+        rows = trtd.owned_rows(H, tiling.group_rows, tiling.n_parts, tiling.part)
+        local = np.zeros((len(rows), W, 4), np.float32)
+        G = tiling.group_rows
+        for k in range(0, len(rows), G):
+            y0 = rows[k]
+            band, _, _, _ = self.oracle.render(scene, g, pc, W, H, camera, rows=(y0, y0 + G), want_hits=False)
+            local[k:k + G] = band[y0:y0 + G]
+        ctypes.memmove(rgba_ptr, local.ctypes.data, local.nbytes)
+
+
+class _Stream:
+    cuda_stream = 0
+
+
 def _worker(rank, world, port, W, H, G, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from oracle import oracle
-        sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(3)
-        rows = trtd.owned_rows(H, G, world, rank)
-        # this rank's compact buffer: its rows of the frame, rendered band by band
-        local = np.zeros((len(rows), W, 4), np.float32)
-        for k in range(0, len(rows), G):
-            y0 = rows[k]
-            band, _, _, _ = oracle.render(sc, g, pc, W, H, rows=(y0, y0 + G), want_hits=False)
-            local[k:k + G] = band[y0:y0 + G]
-        local = torch.from_numpy(local)
-        gathered = torch.empty(world * len(rows), W, 4)
-        dist.all_gather_into_tensor(gathered, local)
-        full = trtd.deinterleave(gathered, H, W, G, world).contiguous()
+        tr = _OracleTracer()
+        sc, g = camera.single_torus_scene(), camera.baseline_camera(W, H)
+        frame = trtd.TiledFrame(tr, W, H, world, rank, torch.device("cpu"), group_rows=G)
+        assert frame.local_rows == H // world and "pipelined" in frame.describe()
+        ok = True
+        # three frames with different maxDepth through the two-deep pipeline; after finish() the
+        # assembled frame is the LAST one, and after each step the frame from two steps ago is retired
+        for depth in (1, 2, 3):
+            frame.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
+        full = frame.finish().clone()
         if rank == 0:
-            want, _, _, _ = oracle.render(sc, g, pc, W, H, want_hits=False)
-            out.put(bool(np.array_equal(full.numpy(), want)))
+            want, _, _, _ = tr.oracle.render(sc, g, camera.baseline_push(3), W, H, want_hits=False)
+            ok = bool(np.array_equal(full.numpy(), want))
+            out.put(ok)
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -164,7 +164,7 @@ def test_render_parity(tr, oracle, name, variant):
         st = tr.stats()
     finally:
         tr.enable_stats(False)
-        tr.set_render_variant("static")
+        tr.set_render_variant("listed")
     # the same queries were executed: bounce/shadow decisions are bit-exact too
     assert st == {**wstats}
 
@@ -179,7 +179,7 @@ def test_render_fp64_nested(tr, oracle, variant):
         check_render(tr, oracle, sc, g, pc, W, H, 0, abi.TRT_SOLVE_F64)
     finally:
         tr.set_solver(abi.TRT_SOLVE_F32)
-        tr.set_render_variant("static")
+        tr.set_render_variant("listed")
 
 
 @pytest.mark.parametrize("name,cam", [("render_pinhole_mirror", 0), ("render_toroidal_plastic", 1)])
@@ -220,7 +220,7 @@ def test_render_dev_rows_and_rendered_data(tr, oracle, variant):
                           hit_ptrs={"t": hit_t.data_ptr()}, rendered_ptr=rend.data_ptr(), stream=s)
         torch.cuda.synchronize()
     finally:
-        tr.set_render_variant("static")
+        tr.set_render_variant("listed")
     wr, wh, wrend, _ = oracle.render(sc, g, pc, W, H, 1, want_rendered=True, nthreads=8)
     np.testing.assert_allclose(rgba.cpu().numpy(), wr, rtol=COLOR_RTOL, atol=COLOR_ATOL)
     np.testing.assert_array_equal(hit_t.cpu().numpy().view(np.uint32), wh["t"].view(np.uint32))
@@ -257,7 +257,7 @@ def test_full_size_properties(tr, variant):
                       stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     finally:
-        tr.set_render_variant("static")
+        tr.set_render_variant("listed")
     hit = hid >= 0
     assert 0.05 < hit.float().mean().item() < 0.5
     P = torch.stack([hb["px"], hb["py"], hb["pz"]], 1)[hit].double()
@@ -336,8 +336,42 @@ def test_tiled_render_matches_full(tr, variant, parts, group):
             tr.render_tiled_dev(sc, g, pc, W, H, abi.trt_tiling(group, parts, p, 0), direct.data_ptr(), stream=s)
         torch.cuda.synchronize()
     finally:
-        tr.set_render_variant("static")
+        tr.set_render_variant("listed")
     assert torch.equal(trtd.deinterleave(gathered, H, W, group, parts), full)
     assert torch.equal(direct, full)
     tt = trtd.deinterleave(t_parts.view(parts, H // parts, W, 1), H, W, group, parts, channels=1).reshape(-1)
     assert torch.equal(tt.view(torch.int32), t_full.view(torch.int32))
+
+
+CAMERAS = [
+    # eye, center, fov, W, H  — the tile classification must stay conservative everywhere
+    ((0.0, 1.5, -4.0), (0.0, 0.0, 0.0), 60.0, 200, 136),     # baseline
+    ((0.0, 0.05, 0.0), (1.0, 0.0, 0.2), 90.0, 168, 104),     # inside the hole, in the torus plane
+    ((0.9, 0.1, 0.3), (-1.0, 0.0, 0.0), 100.0, 136, 136),    # inside the bounding sphere, next to the tube
+    ((0.0, 3.0, 0.01), (0.0, 0.0, 0.0), 45.0, 128, 160),     # straight down the axis (a = 0 rays)
+    ((6.0, 0.0, 0.0), (0.0, 0.0, 0.0), 25.0, 264, 72),       # edge-on, narrow fov (dy = 0 rows)
+    ((-2.0, 0.7, 2.5), (3.0, 0.0, -2.0), 120.0, 152, 88),    # wide angle, torus off-centre
+    ((0.0, 1.5, -4.0), (0.0, 1.5, -9.0), 60.0, 96, 64),      # torus behind the camera
+    ((0.3, 0.26, 1.0), (0.0, 0.0, 0.9), 70.0, 120, 120),     # skimming the top of the tube
+    ((40.0, 12.0, -25.0), (0.0, 0.0, 0.0), 5.0, 232, 168),   # far away, tiny fov
+]
+
+
+@pytest.mark.parametrize("variant", ["persistent", "listed"])
+@pytest.mark.parametrize("cam", range(len(CAMERAS)))
+@pytest.mark.parametrize("scene", ["single", "nested8", "thin_offset"])
+def test_tile_classification_is_conservative(tr, oracle, cam, variant, scene):
+    """Frames from cameras around, inside and behind the tori: the CLEAR/LIVE classification may
+    never change a pixel — first-hit records bit-exact, query counts identical."""
+    eye, center, fov, W, H = CAMERAS[cam]
+    sc = SCENES[scene]()
+    g = camera.globals_for(eye, center, W, H, fov_deg=fov)
+    pc = camera.baseline_push(4)
+    tr.set_render_variant(variant)
+    tr.enable_stats(True)
+    try:
+        _, _, wstats = check_render(tr, oracle, sc, g, pc, W, H, 0)
+        assert tr.stats() == wstats
+    finally:
+        tr.enable_stats(False)
+        tr.set_render_variant("listed")

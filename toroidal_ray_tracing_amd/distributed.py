@@ -38,7 +38,12 @@ def deinterleave(gathered, H, W, group_rows, n_parts, channels=4):
 
 
 class TiledFrame:
-    """Framebuffer + first-hit streams of one rank, and the per-frame render/gather step."""
+    """Framebuffer + first-hit streams of one rank, and the per-frame render/gather step.
+
+    With world > 1 the step is software-pipelined over two buffer sets: the all-gather of
+    frame k (RCCL, asynchronous on the process group's stream) runs while frame k+1 renders, so
+    the frame rate is max(render, gather) instead of their sum; ``finish()`` drains the pipe.
+    """
 
     def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=DEFAULT_GROUP_ROWS,
                  gather=True):
@@ -50,35 +55,60 @@ class TiledFrame:
         self.local_rows = tracer.tiling_rows(self.tiling, H) if world > 1 else H
         self.local_pixels = self.local_rows * W
         f32 = dict(dtype=torch.float32, device=device)
-        self.local = torch.empty(self.local_rows, W, 4, **f32)
+        nbuf = 2 if self.gather else 1
+        self.locals = [torch.empty(self.local_rows, W, 4, **f32) for _ in range(nbuf)]
         self.hits = {k: torch.empty(self.local_pixels, **f32) for k in want_hits if k != "id"}
         if "id" in want_hits:
             self.hits["id"] = torch.empty(self.local_pixels, dtype=torch.int32, device=device)
         # concatenated along dim 0 (the form both RCCL and gloo accept); viewed as [N, H/N, W, 4]
-        self.gathered = torch.empty(world * self.local_rows, W, 4, **f32) if self.gather else None
-        self.full = torch.empty(H, W, 4, **f32) if self.gather else self.local
+        self.gathered = [torch.empty(world * self.local_rows, W, 4, **f32) for _ in range(nbuf)] if self.gather else None
+        self.full = torch.empty(H, W, 4, **f32) if self.gather else self.locals[0]
+        self._pending = [None] * nbuf   # in-flight all-gather of each buffer set
+        self._k = 0
+
+    @property
+    def local(self):
+        return self.locals[0]
 
     def describe(self):
         if self.world == 1:
             return "single GPU, full frame"
         return (f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; "
-                f"{'all_gather_into_tensor(rgba32f) + de-interleave' if self.gather else 'no gather'}")
+                f"{'all_gather_into_tensor(rgba32f) pipelined behind the next frame + de-interleave' if self.gather else 'no gather'}")
+
+    def _retire(self, b):
+        """Wait for the gather of buffer set b and assemble its frame."""
+        if self._pending[b] is not None:
+            self._pending[b].wait()   # orders the current stream behind the collective
+            self._pending[b] = None
+            self.full.copy_(deinterleave(self.gathered[b], self.H, self.W, self.group_rows, self.world))
 
     def render(self, scene, g, pc, camera, stream, events=None):
-        """One frame: render this rank's rows; gather + de-interleave when world > 1.
-        `events` = (start, end) torch.cuda.Events recorded around the render kernel only."""
+        """One frame: render this rank's rows; when world > 1 start the all-gather of this frame
+        and finish (wait + de-interleave) the frame that used this buffer set two steps ago.
+        `events` = (start, end) torch.cuda.Events recorded around the render launches only."""
         hp = {k: v.data_ptr() for k, v in self.hits.items()}
+        b = self._k % len(self.locals)
+        self._k += 1
+        if self.gather:
+            self._retire(b)
         if events:
             events[0].record(stream)
         if self.world == 1:
-            self.tr.render_dev(scene, g, pc, self.W, self.H, self.local.data_ptr(), camera=camera,
+            self.tr.render_dev(scene, g, pc, self.W, self.H, self.locals[b].data_ptr(), camera=camera,
                                hit_ptrs=hp, stream=stream.cuda_stream)
         else:
-            self.tr.render_tiled_dev(scene, g, pc, self.W, self.H, self.tiling, self.local.data_ptr(),
+            self.tr.render_tiled_dev(scene, g, pc, self.W, self.H, self.tiling, self.locals[b].data_ptr(),
                                      camera=camera, hit_ptrs=hp, stream=stream.cuda_stream)
         if events:
             events[1].record(stream)
         if self.gather:
-            dist.all_gather_into_tensor(self.gathered, self.local)
-            self.full.copy_(deinterleave(self.gathered, self.H, self.W, self.group_rows, self.world))
+            self._pending[b] = dist.all_gather_into_tensor(self.gathered[b], self.locals[b], async_op=True)
+        return self.full
+
+    def finish(self):
+        """Drain the pipeline: every frame rendered so far is gathered and assembled."""
+        if self.gather:
+            for b in range(len(self.locals)):
+                self._retire((self._k + b) % len(self.locals))
         return self.full
