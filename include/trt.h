@@ -197,6 +197,15 @@ int trt_render_tiled_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
                          float* rgba_dev, trt_hits* first_hit_dev, trt_rendered_data* rendered_dev,
                          void* stream);
 
+/* ---- post pass: the tonemap of REFL/shaders/post.frag:33-37 ------------------------------ */
+/* out = pow(in, 1/2.2) on all four channels (GLSL pow(x,y) = exp2(y*log2(x)); x <= 0 or NaN -> 0).
+ * f32_out (n_pixels*4 floats) and/or unorm8_out (n_pixels*4 bytes, R,G,B,A, round-to-nearest of
+ * clamp(out,0,1)*255 — the 8-bit image a swapchain presents; 4x smaller to all-gather) may be
+ * NULL.  exp2/log2 are evaluated with a fixed fma polynomial, so the bytes are
+ * reproducible bit for bit on any IEEE machine. */
+int trt_post_dev(trt_ctx* ctx, const float* rgba_in_dev, uint64_t n_pixels, float* f32_out_dev,
+                 uint8_t* unorm8_out_dev, void* stream);
+
 /* Counters of the last render or trace call made with counting enabled. */
 int trt_enable_stats(trt_ctx* ctx, int on);
 int trt_get_stats(trt_ctx* ctx, trt_stats* out); /* synchronises the ctx's last stream   */

@@ -57,6 +57,8 @@ def lib():
         L.oracle_torus_first_hit.argtypes = [C.POINTER(abi.trt_torus), abi.f32p, abi.f32p,
                                              C.c_float, C.c_float, C.c_int,
                                              C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.oracle_post.restype = C.c_int
+        L.oracle_post.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.oracle_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -138,3 +140,12 @@ def torus_first_hit(torus, o, d, tmin=0.001, tmax=10000.0, precision=abi.TRT_SOL
     hit = lib().oracle_torus_first_hit(C.byref(T), oo, dd, tmin, tmax, precision, C.byref(t),
                                        C.byref(ne))
     return (t.value if hit else None), ne.value
+
+
+def post(rgba):
+    """Tonemap pass: returns (float32 image, uint8 image) of the same shape as rgba (…,4)."""
+    a = np.ascontiguousarray(rgba, np.float32)
+    f = np.empty_like(a)
+    u = np.empty(a.shape, np.uint8)
+    _check(lib().oracle_post(abi.ptr(a), a.size // 4, abi.ptr(f), abi.ptr(u)), "post")
+    return f, u

@@ -582,3 +582,67 @@ int oracle_torus_first_hit(const trt_torus* T, const float* o, const float* d, f
   if(evals) *evals = ne;
   return hit;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* post pass: pow(c, 1/2.2) of REFL/shaders/post.frag:33-37, GLSL pow = exp2(y*log2(x)),   */
+/* with the fixed log2/exp2 polynomials of DESIGN.md §4 (same operations as the kernel)    */
+/* ------------------------------------------------------------------------------------ */
+static inline float log2_poly(float x)
+{
+  int32_t bits;
+  memcpy(&bits, &x, 4);
+  int   e = (bits >> 23) - 127;
+  int32_t mb = (bits & 0x007fffff) | 0x3f800000;
+  float m;
+  memcpy(&m, &mb, 4);
+  if(m > 1.41421354f) { m *= 0.5f; e += 1; }
+  const float s  = (m - 1.0f) / (m + 1.0f);
+  const float s2 = s * s;
+  float p = fmaf(s2, 0.222222222f, 0.285714286f);
+  p = fmaf(s2, p, 0.4f);
+  p = fmaf(s2, p, 0.666666667f);
+  p = fmaf(s2, p, 2.0f);
+  return fmaf(p * s, 1.44269504f, (float)e);
+}
+
+static inline float exp2_poly(float y)
+{
+  y = fminf(fmaxf(y, -126.0f), 127.0f);
+  const float n = floorf(y);
+  const float z = (y - n) * 0.693147181f;
+  float p = fmaf(z, 2.75573192e-6f, 2.48015873e-5f);
+  p = fmaf(z, p, 1.98412698e-4f);
+  p = fmaf(z, p, 1.38888889e-3f);
+  p = fmaf(z, p, 8.33333333e-3f);
+  p = fmaf(z, p, 4.16666667e-2f);
+  p = fmaf(z, p, 1.66666667e-1f);
+  p = fmaf(z, p, 0.5f);
+  p = fmaf(z, p, 1.0f);
+  p = fmaf(z, p, 1.0f);
+  int32_t pb;
+  memcpy(&pb, &p, 4);
+  pb += (int32_t)n << 23;
+  memcpy(&p, &pb, 4);
+  return p;
+}
+
+static inline float post_gamma(float c)
+{
+  if(!(c > 0.0f)) return 0.0f;
+  if(c > 3.0e38f) return c;
+  if(c < 1.17549435e-38f) return 0.0f;
+  return exp2_poly(0.454545455f * log2_poly(c));  /* post.frag:35-36, gamma = 1/2.2 */
+}
+
+/* Same contract as trt_post_dev on host buffers. */
+int oracle_post(const float* rgba_in, uint64_t n_pixels, float* f32_out, uint8_t* unorm8_out)
+{
+  if(n_pixels && !rgba_in) return TRT_E_INVALID;
+  for(uint64_t i = 0; i < 4 * n_pixels; ++i)
+  {
+    const float o = post_gamma(rgba_in[i]);
+    if(f32_out) f32_out[i] = o;
+    if(unorm8_out) unorm8_out[i] = (uint8_t)rintf(fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f);
+  }
+  return TRT_OK;
+}

@@ -375,3 +375,38 @@ def test_tile_classification_is_conservative(tr, oracle, cam, variant, scene):
     finally:
         tr.enable_stats(False)
         tr.set_render_variant("listed")
+
+
+def test_post_pass_bit_exact(tr, oracle):
+    """trt_post_dev (tonemap of post.frag) — float and UNORM8 outputs bit for bit equal to the
+    oracle: the exp2/log2 polynomials use only correctly rounded operations."""
+    import torch
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0, 1.2, 1_000_003 * 4), np.logspace(-40, 38, 4001), [0, -2.5, np.nan, np.inf, 1, 1e-45, 0.8]])
+    x = np.float32(x[: (len(x) // 4) * 4]).reshape(-1, 4)
+    d_in = torch.from_numpy(x).to(dev)
+    d_f = torch.empty_like(d_in)
+    d_u = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    tr.post_dev(d_in.data_ptr(), x.shape[0], d_f.data_ptr(), d_u.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    wf, wu = oracle.post(x)
+    np.testing.assert_array_equal(d_f.cpu().numpy().view(np.uint32), wf.view(np.uint32))
+    np.testing.assert_array_equal(d_u.cpu().numpy(), wu)
+    # either output alone, empty input, and a rendered frame end to end
+    d_u.zero_()
+    tr.post_dev(d_in.data_ptr(), x.shape[0], 0, d_u.data_ptr(), stream=s)
+    tr.post_dev(d_in.data_ptr(), 0, d_f.data_ptr(), 0, stream=s)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_u.cpu().numpy(), wu)
+    W, H = 256, 128
+    sc, g, pc = camera.single_torus_scene(material=camera.PLASTIC), camera.baseline_camera(W, H), camera.baseline_push(3)
+    img = torch.empty(H, W, 4, device=dev)
+    out8 = torch.empty(H, W, 4, dtype=torch.uint8, device=dev)
+    tr.render_dev(sc, g, pc, W, H, img.data_ptr(), stream=s)
+    tr.post_dev(img.data_ptr(), W * H, 0, out8.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    _, w8 = oracle.post(img.cpu().numpy())
+    np.testing.assert_array_equal(out8.cpu().numpy(), w8)
+    assert (out8[..., 3] == 255).all() and out8[..., :3].float().std() > 1

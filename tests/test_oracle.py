@@ -242,3 +242,25 @@ def test_scene_validation(oracle):
                 abi.Scene([((0, 0, 0), 1.0, 0.2, 3)], [camera.MIRROR])]:  # matId out of range
         with pytest.raises(RuntimeError, match="TRT_E_SCENE"):
             oracle.render(bad, g, pc, 8, 8)
+
+
+def test_post_gamma_matches_pow(oracle):
+    """post.frag:35-36: fragColor = pow(texture, 1/2.2) on all four channels; the fixed
+    log2/exp2 polynomials stay within a few ulp of the real power on the range colours live in."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 1, 200_000), rng.uniform(1, 200, 50_000),
+                        np.logspace(-30, 30, 20_001)]).astype(np.float32)
+    x = x[: (len(x) // 4) * 4].reshape(-1, 4)
+    f, u = oracle.post(x)
+    ref = np.power(x.astype(np.float64), 1 / 2.2)
+    col = (x > 1e-6) & (x < 1e3)
+    assert np.max(np.abs(f[col] - ref[col]) / ref[col]) < 1.5e-6   # y*log2(x) in FP32, as GLSL evaluates it
+    wide = x > 1.2e-38
+    assert np.max(np.abs(f[wide] - ref[wide]) / ref[wide]) < 5e-6
+    np.testing.assert_array_equal(u, np.rint(np.clip(f, 0, 1) * 255).astype(np.uint8))
+    # special values: non-positive / NaN -> 0, +inf -> inf, 1 -> 1 exactly, alpha 1 stays 1
+    s = np.float32([[0.0, -1.0, np.nan, np.inf], [1.0, 0.8, 1e-45, 1.0]])
+    f, u = oracle.post(s)
+    assert f[0, 0] == 0 and f[0, 1] == 0 and f[0, 2] == 0 and np.isposinf(f[0, 3])
+    assert f[1, 0] == 1.0 and f[1, 3] == 1.0 and f[1, 2] == 0 and abs(f[1, 1] - 0.8 ** (1 / 2.2)) < 1e-7
+    assert u[1].tolist() == [255, 230, 0, 255] and u[0].tolist() == [0, 0, 0, 255]

@@ -90,5 +90,13 @@ render_case("C4' 8 nested tori, FP32 solve", camera.nested_tori_scene(), camera.
 pc = camera.baseline_push(5); pc.rho = 4.0
 render_case("toroidal camera, interior R=6", camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC),
             camera.toroidal_camera(W, W), pc, W, W, cam=1)
+n = 4096 * 4096
+img = torch.rand(n, 4, device=dev)
+o8 = torch.empty(n, 4, dtype=torch.uint8, device=dev)
+of = torch.empty(n, 4, device=dev)
+ms = timeit(lambda: tr.post_dev(img.data_ptr(), n, 0, o8.data_ptr(), stream=s.cuda_stream))
+print(f"{'post pass 4096^2 -> unorm8':34s} {'post':10s} {ms:8.4f} ms  {20 * n / ms / 1e6:7.0f} GB/s ({20 * n / ms / 8e9 * 100:4.1f}% of 8 TB/s, 20 B/px)")
+ms = timeit(lambda: tr.post_dev(img.data_ptr(), n, of.data_ptr(), 0, stream=s.cuda_stream))
+print(f"{'post pass 4096^2 -> f32':34s} {'post':10s} {ms:8.4f} ms  {32 * n / ms / 1e6:7.0f} GB/s ({32 * n / ms / 8e9 * 100:4.1f}% of 8 TB/s, 32 B/px)")
 W = 8192
 render_case("C5 shape on ONE GPU: 8192^2", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W, variants=("listed",))

@@ -561,3 +561,19 @@ extern "C" int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc
   TRT_HIP(ctx, hipStreamSynchronize(nullptr));
   return TRT_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// post pass
+// ------------------------------------------------------------------------------------------
+extern "C" int trt_post_dev(trt_ctx* ctx, const float* rgba_in, uint64_t n_pixels, float* f32_out,
+                            uint8_t* unorm8_out, void* stream)
+{
+  if(!ctx) return TRT_E_INVALID;
+  if(n_pixels && !rgba_in) return fail(ctx, TRT_E_INVALID, "trt_post: NULL input image");
+  if(((uintptr_t)rgba_in | (uintptr_t)f32_out) & 15 || ((uintptr_t)unorm8_out & 3))
+    return fail(ctx, TRT_E_INVALID, "trt_post: images must be 16-byte (float) / 4-byte (unorm8) aligned");
+  TRT_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->last_stream = (hipStream_t)stream;
+  TRT_HIP(ctx, launch_post(rgba_in, n_pixels, f32_out, unorm8_out, ctx->n_cus, (hipStream_t)stream));
+  return TRT_OK;
+}

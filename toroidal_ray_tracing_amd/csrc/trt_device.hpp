@@ -504,4 +504,50 @@ __device__ __forceinline__ void raygen(const trt_globals& g, const ToroCam& tc, 
   dir          = mat4_mul(g.viewInverse, tn.x, tn.y, tn.z, 0.0f);
 }
 
+// ------------------------------------------------------------------------------------------
+// post pass: pow(c, 1/2.2) with exact-operation log2 / exp2 (REFL/shaders/post.frag:33-37)
+// ------------------------------------------------------------------------------------------
+// log2(x), x a positive normal float: x = 2^e·m, m ∈ [√½, √2); ln(m) = 2·atanh(s), s = (m-1)/(m+1),
+// odd series to s⁹ (|s| <= 0.172: truncation < 5e-10); only + - * / fma and integer bit moves.
+__device__ __forceinline__ float log2_poly(float x)
+{
+  int   bits = __float_as_int(x);
+  int   e    = (bits >> 23) - 127;
+  float m    = __int_as_float((bits & 0x007fffff) | 0x3f800000);
+  if(m > 1.41421354f) { m *= 0.5f; e += 1; }
+  const float s  = (m - 1.0f) / (m + 1.0f);
+  const float s2 = s * s;
+  float p = fma_(s2, 0.222222222f, 0.285714286f);   // 2/9, 2/7
+  p = fma_(s2, p, 0.4f);                             // 2/5
+  p = fma_(s2, p, 0.666666667f);                     // 2/3
+  p = fma_(s2, p, 2.0f);
+  return fma_(p * s, 1.44269504f, (float)e);         // ln -> log2, plus the exponent
+}
+// 2^y for y in [-126, 127]: n = floor(y), 2^f = exp(f·ln2) by its Taylor polynomial to f⁹, then
+// the exponent is added to the bit pattern.
+__device__ __forceinline__ float exp2_poly(float y)
+{
+  y = min_(max_(y, -126.0f), 127.0f);
+  const float n = floorf(y);
+  const float z = (y - n) * 0.693147181f;
+  float p = fma_(z, 2.75573192e-6f, 2.48015873e-5f);  // 1/9!, 1/8!
+  p = fma_(z, p, 1.98412698e-4f);                     // 1/7!
+  p = fma_(z, p, 1.38888889e-3f);                     // 1/6!
+  p = fma_(z, p, 8.33333333e-3f);                     // 1/5!
+  p = fma_(z, p, 4.16666667e-2f);                     // 1/4!
+  p = fma_(z, p, 1.66666667e-1f);                     // 1/3!
+  p = fma_(z, p, 0.5f);
+  p = fma_(z, p, 1.0f);
+  p = fma_(z, p, 1.0f);
+  return __int_as_float(__float_as_int(p) + ((int)n << 23));
+}
+// pow(c, 1/2.2) as the post shader applies it; non-positive and NaN inputs give 0, +inf stays.
+__device__ __forceinline__ float post_gamma(float c)
+{
+  if(!(c > 0.0f)) return 0.0f;
+  if(c > 3.0e38f) return c;
+  if(c < 1.17549435e-38f) return 0.0f;  // subnormal colours
+  return exp2_poly(0.454545455f * log2_poly(c));
+}
+
 }  // namespace trt

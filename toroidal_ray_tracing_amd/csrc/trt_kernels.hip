@@ -866,6 +866,40 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
 }
 
 // ------------------------------------------------------------------------------------------
+// post pass (tonemap): streaming, one pixel per lane, 16 B in, 16 B and/or 4 B out
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void post_kernel(const float4* __restrict__ in, uint64_t n, float4* __restrict__ f32_out,
+                                                   uint32_t* __restrict__ u8_out)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  {
+    const float4 c = in[i];
+    const float4 o = make_float4(post_gamma(c.x), post_gamma(c.y), post_gamma(c.z), post_gamma(c.w));
+    if(f32_out) f32_out[i] = o;
+    if(u8_out)
+    {
+      // UNORM8: round-to-nearest-even of clamp(o, 0, 1)·255 (v_rndne via rintf), R in the low byte
+      const uint32_t r = (uint32_t)rintf(min_(max_(o.x, 0.0f), 1.0f) * 255.0f);
+      const uint32_t g = (uint32_t)rintf(min_(max_(o.y, 0.0f), 1.0f) * 255.0f);
+      const uint32_t b = (uint32_t)rintf(min_(max_(o.z, 0.0f), 1.0f) * 255.0f);
+      const uint32_t a = (uint32_t)rintf(min_(max_(o.w, 0.0f), 1.0f) * 255.0f);
+      u8_out[i] = r | (g << 8) | (b << 16) | (a << 24);
+    }
+  }
+}
+
+hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, hipStream_t stream)
+{
+  if(n == 0) return hipSuccess;
+  const uint64_t want = (n + 255) / 256, cap = (uint64_t)n_cus * 16;
+  hipLaunchKernelGGL(post_kernel, dim3((uint32_t)(want < cap ? want : cap)), dim3(256), 0, stream,
+                     reinterpret_cast<const float4*>(in), n, reinterpret_cast<float4*>(f32_out),
+                     reinterpret_cast<uint32_t*>(u8_out));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream)

@@ -128,6 +128,13 @@ class Tracer:
     def tiling_rows(self, tiling, H):
         return int(self._L.trt_tiling_rows(C.byref(tiling), H))
 
+    def post_dev(self, rgba_ptr, n_pixels, f32_out_ptr=0, unorm8_out_ptr=0, stream=0):
+        """Tonemap pass of post.frag (pow(c, 1/2.2)) on device buffers."""
+        self._check(self._L.trt_post_dev(self._h, C.c_void_p(int(rgba_ptr) or None), int(n_pixels),
+                                         C.c_void_p(int(f32_out_ptr) or None),
+                                         C.c_void_p(int(unorm8_out_ptr) or None),
+                                         C.c_void_p(int(stream) or None)))
+
     def raytrace(self, scene, g, light, max_depth, clear_color, W, H, rgba_ptr, camera=0, rho=0.0,
                  **kw):
         """Mirror of ``HelloVulkan::raytrace(cmdBuf, clearColor)``: fills PushConstantRay from
