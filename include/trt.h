@@ -206,6 +206,29 @@ int trt_render_tiled_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
 int trt_post_dev(trt_ctx* ctx, const float* rgba_in_dev, uint64_t n_pixels, float* f32_out_dev,
                  uint8_t* unorm8_out_dev, void* stream);
 
+/* ---- point-cloud re-projection: the consumer of the captures (SEC = ray_tracing__before_second) --- */
+/* Point, SEC/shaders/host_device.h:113-117: what loadPoints()/createCloudDataBuffer()
+ * (SEC/hello_vulkan.cpp:496-660) build from renderedPosition*.txt / renderedColor*.txt. */
+typedef struct trt_point {
+  float pos[4];
+  float color[4];
+} trt_point; /* 32 bytes */
+
+/* Rasterises the points as the reference's POINT_LIST pipeline does (SEC/hello_vulkan.cpp:143-270,
+ * 313-330; SEC/shaders/vert_shader.vert:43-52, frag_shader.frag:40-45):
+ *   clip = viewProj * (pos.xyz, 1); a point whose vertex is outside the clip volume
+ *   (-w <= x,y <= w, 0 <= z <= w, w > 0) is discarded; window position
+ *   xf = (x/w*0.5+0.5)*W, yf = (y/w*0.5+0.5)*H, depth z/w quantised to 24-bit UNORM (the
+ *   offscreen depth format X8_D24, SEC/hello_vulkan.h) with round-to-nearest;
+ *   the point covers every pixel whose centre (i+0.5, j+0.5) satisfies
+ *   xf - size/2 <= i+0.5 < xf + size/2 (same in y), size = gl_PointSize = 2.5;
+ *   depth test LESS against a buffer cleared to 1.0, depth write on; equal depths keep the
+ *   EARLIER point (primitive order); colour (color.xyz, 1); untouched pixels = clearColor.
+ * rgba_dev: W*H*4 floats, row-major. */
+int trt_splat_dev(trt_ctx* ctx, const trt_point* points_dev, uint64_t n_points, const float* viewProj,
+                  uint32_t W, uint32_t H, const float* clearColor, float point_size, float* rgba_dev,
+                  void* stream);
+
 /* Counters of the last render or trace call made with counting enabled. */
 int trt_enable_stats(trt_ctx* ctx, int on);
 int trt_get_stats(trt_ctx* ctx, trt_stats* out); /* synchronises the ctx's last stream   */

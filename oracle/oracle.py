@@ -59,6 +59,9 @@ def lib():
                                              C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.oracle_post.restype = C.c_int
         L.oracle_post.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.oracle_splat.restype = C.c_int
+        L.oracle_splat.argtypes = [C.c_void_p, C.c_uint64, abi.f32p, C.c_uint32, C.c_uint32, abi.f32p, C.c_float,
+                                   C.c_void_p]
         L.oracle_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -149,3 +152,13 @@ def post(rgba):
     u = np.empty(a.shape, np.uint8)
     _check(lib().oracle_post(abi.ptr(a), a.size // 4, abi.ptr(f), abi.ptr(u)), "post")
     return f, u
+
+
+def splat(points, view_proj, W, H, clear=(0.8, 0.8, 0.8, 1.0), point_size=2.5):
+    """points: (n, 8) float32 array of trt_point records (pos.xyzw, color.xyzw)."""
+    pts = np.ascontiguousarray(points, np.float32)
+    vp = (C.c_float * 16)(*np.asarray(view_proj, np.float32).T.reshape(-1).tolist())
+    cc = (C.c_float * 4)(*[float(v) for v in clear])
+    out = np.empty((H, W, 4), np.float32)
+    _check(lib().oracle_splat(abi.ptr(pts), len(pts), vp, W, H, cc, point_size, abi.ptr(out)), "splat")
+    return out

@@ -646,3 +646,59 @@ int oracle_post(const float* rgba_in, uint64_t n_pixels, float* f32_out, uint8_t
   }
   return TRT_OK;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* point-cloud re-projection (SEC = ray_tracing__before_second): sequential rasteriser     */
+/* ------------------------------------------------------------------------------------ */
+/* Same contract as trt_splat_dev: points in primitive order, depth test LESS on a 24-bit
+ * UNORM buffer cleared to 1.0 (SEC/hello_vulkan.cpp:235-241, SEC/main.cpp:221-223), point size
+ * 2.5 (SEC/shaders/vert_shader.vert:50), colour of the point (frag_shader.frag:40-45). */
+int oracle_splat(const trt_point* pts, uint64_t n_points, const float* vp, uint32_t W, uint32_t H,
+                 const float* clear, float point_size, float* rgba)
+{
+  if(!vp || !clear || !rgba || (n_points && !pts) || !W || !H) return TRT_E_INVALID;
+  const size_t npx = (size_t)W * H;
+  uint32_t* depth = (uint32_t*)malloc(npx * sizeof(uint32_t));
+  if(!depth) return TRT_E_NOMEM;
+  for(size_t i = 0; i < npx; ++i)
+  {
+    depth[i] = 0x00FFFFFFu;                                                  /* clear depth 1.0 */
+    memcpy(&rgba[4 * i], clear, 4 * sizeof(float));
+  }
+  const float half = point_size * 0.5f;
+  for(uint64_t i = 0; i < n_points; ++i)
+  {
+    const float* p = pts[i].pos;
+    const float cx = fmaf(vp[12], 1.0f, fmaf(vp[8], p[2], fmaf(vp[4], p[1], vp[0] * p[0])));   /* vert:51 */
+    const float cy = fmaf(vp[13], 1.0f, fmaf(vp[9], p[2], fmaf(vp[5], p[1], vp[1] * p[0])));
+    const float cz = fmaf(vp[14], 1.0f, fmaf(vp[10], p[2], fmaf(vp[6], p[1], vp[2] * p[0])));
+    const float cw = fmaf(vp[15], 1.0f, fmaf(vp[11], p[2], fmaf(vp[7], p[1], vp[3] * p[0])));
+    if(!(cw > 0.0f && cx >= -cw && cx <= cw && cy >= -cw && cy <= cw && cz >= 0.0f && cz <= cw))
+      continue;
+    const float iw = 1.0f / cw;
+    const float xf = fmaf(cx * iw, 0.5f, 0.5f) * (float)W;
+    const float yf = fmaf(cy * iw, 0.5f, 0.5f) * (float)H;
+    const uint32_t z24 = (uint32_t)rintf((cz * iw) * 16777215.0f);
+    int x0 = (int)ceilf(xf - half - 0.5f), x1 = (int)ceilf(xf + half - 0.5f);
+    int y0 = (int)ceilf(yf - half - 0.5f), y1 = (int)ceilf(yf + half - 0.5f);
+    if(x0 < 0) x0 = 0;
+    if(y0 < 0) y0 = 0;
+    if(x1 > (int)W) x1 = (int)W;
+    if(y1 > (int)H) y1 = (int)H;
+    for(int y = y0; y < y1; ++y)
+      for(int x = x0; x < x1; ++x)
+      {
+        const size_t k = (size_t)y * W + x;
+        if(z24 < depth[k])                                                   /* VK_COMPARE_OP_LESS */
+        {
+          depth[k] = z24;
+          rgba[4 * k + 0] = pts[i].color[0];
+          rgba[4 * k + 1] = pts[i].color[1];
+          rgba[4 * k + 2] = pts[i].color[2];
+          rgba[4 * k + 3] = 1.0f;                                            /* frag:44 */
+        }
+      }
+  }
+  free(depth);
+  return TRT_OK;
+}

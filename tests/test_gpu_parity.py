@@ -410,3 +410,56 @@ def test_post_pass_bit_exact(tr, oracle):
     _, w8 = oracle.post(img.cpu().numpy())
     np.testing.assert_array_equal(out8.cpu().numpy(), w8)
     assert (out8[..., 3] == 255).all() and out8[..., :3].float().std() > 1
+
+
+def test_splat_bit_exact(tr, oracle):
+    """trt_splat_dev (point-cloud re-projection of ray_tracing__before_second) against the
+    sequential rasteriser of the oracle: random clouds with duplicated points (depth ties),
+    clipped and degenerate points, several image sizes."""
+    import torch
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(21)
+    for W, H, n, eye in [(200, 136, 50_000, (1.0, 2.0, 6.0)), (64, 64, 300_000, (0.0, 0.0, 4.0)), (333, 77, 1000, (5.0, 0.1, 0.2))]:
+        pts = np.zeros((n, 8), np.float32)
+        pts[:, :3] = rng.uniform(-3, 3, (n, 3))
+        pts[:, 4:7] = rng.uniform(0, 1, (n, 3))
+        pts[n // 2:n // 2 + n // 10] = pts[:n // 10]                  # duplicates -> equal depth, different colour
+        pts[n // 2:n // 2 + n // 10, 4:7] = rng.uniform(0, 1, (n // 10, 3))
+        pts[::97, :3] = np.finfo(np.float32).min                       # the "-nan" convention of loadPoints()
+        pts[5::101, 0] = np.nan
+        vp = camera.perspective_vk(65, W / H) @ camera.look_at(eye, (0, 0, 0))
+        d_pts = torch.from_numpy(pts).to(dev)
+        out = torch.empty(H, W, 4, device=dev)
+        tr.splat_dev(d_pts.data_ptr(), n, vp, W, H, out.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        want = oracle.splat(pts, vp, W, H)
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # no points at all: the clear colour everywhere
+    tr.splat_dev(0, 0, vp, W, H, out.data_ptr(), clear=(0.1, 0.2, 0.3, 1.0), stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.tensor([0.1, 0.2, 0.3, 1.0], device=dev).expand(H, W, 4))
+
+
+def test_capture_then_reproject(tr, oracle):
+    """The research pipeline end to end: toroidal capture (RenderedData pos + colour) ->
+    Point cloud (createCloudDataBuffer: pos.w = color.w = 0) -> re-projection from a pinhole
+    viewpoint, GPU == oracle bit for bit on the same captured data."""
+    import torch
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    W = H = 256
+    sc = camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC)
+    g, pc = camera.toroidal_camera(W, H), abi.make_push(max_depth=3, rho=4.0)
+    rend = torch.empty(W * H, 16, device=dev)
+    tr.render_dev(sc, g, pc, W, H, 0, camera=1, rendered_ptr=rend.data_ptr(), stream=s)
+    cloud = torch.zeros(W * H, 8, device=dev)
+    cloud[:, :3] = rend[:, 0:3]
+    cloud[:, 4:7] = rend[:, 4:7]
+    vp = camera.perspective_vk(60, 1.0) @ camera.look_at((0.5, 1.0, -1.0), (6.0, 0.0, 2.0))
+    out = torch.empty(H, W, 4, device=dev)
+    tr.splat_dev(cloud.data_ptr(), W * H, vp, W, H, out.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    want = oracle.splat(cloud.cpu().numpy(), vp, W, H)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert 0.02 < (out[..., :3] != 0.8).any(dim=2).float().mean().item() < 0.98

@@ -264,3 +264,52 @@ def test_post_gamma_matches_pow(oracle):
     assert f[0, 0] == 0 and f[0, 1] == 0 and f[0, 2] == 0 and np.isposinf(f[0, 3])
     assert f[1, 0] == 1.0 and f[1, 3] == 1.0 and f[1, 2] == 0 and abs(f[1, 1] - 0.8 ** (1 / 2.2)) < 1e-7
     assert u[1].tolist() == [255, 230, 0, 255] and u[0].tolist() == [0, 0, 0, 255]
+
+
+def _cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    pts = np.zeros((n, 8), np.float32)
+    pts[:, :3] = rng.uniform(-3, 3, (n, 3))
+    pts[:, 4:7] = rng.uniform(0, 1, (n, 3))
+    return pts
+
+
+def test_splat_semantics(oracle):
+    """SEC point pipeline: size 2.5, depth LESS on D24 cleared to 1, first point wins ties,
+    vertices outside the clip volume are discarded (SEC/hello_vulkan.cpp:143-270)."""
+    W, H = 64, 48
+    vp = camera.perspective_vk(60, W / H) @ camera.look_at((0, 0, 5), (0, 0, 0))
+    pts = np.zeros((6, 8), np.float32)
+    pts[0, :3], pts[0, 4:7] = (0, 0, 0), (1, 0, 0)        # red, at the centre
+    pts[1, :3], pts[1, 4:7] = (0, 0, 1), (0, 1, 0)        # green, nearer: wins
+    pts[2, :3], pts[2, 4:7] = (0, 0, 1), (0, 0, 1)        # blue, same depth as green, later: loses
+    pts[3, :3], pts[3, 4:7] = (0, 0, 6), (1, 1, 0)        # behind the camera: clipped
+    pts[4, :3] = np.finfo(np.float32).min                 # "-nan" entries of loadPoints(): clipped
+    pts[5, :3], pts[5, 4:7] = (100, 0, 0), (1, 0, 1)      # outside the frustum: clipped (even if it would overlap)
+    img = oracle.splat(pts, vp, W, H)
+    drawn = np.any(img[..., :3] != np.float32(0.8), axis=2)
+    assert drawn.sum() in (4, 6, 9) and np.all(img[drawn][:, :3] == [0, 1, 0]) and np.all(img[..., 3] == 1)
+    assert np.all(img[~drawn] == np.float32([0.8, 0.8, 0.8, 1.0]))
+    # swap the tie: blue first -> blue wins
+    img2 = oracle.splat(pts[[0, 2, 1, 3, 4, 5]], vp, W, H)
+    assert np.all(img2[drawn][:, :3] == [0, 0, 1])
+    # coverage rule: centres c with xf-1.25 <= c < xf+1.25
+    one = np.zeros((1, 8), np.float32)
+    one[0, 4:7] = 1
+    for xw, want in [(32.0, [31, 32]), (32.5, [31, 32, 33]), (32.25, [31, 32]), (31.75, [30, 31, 32]), (32.74, [31, 32, 33]), (32.76, [32, 33])]:
+        # place the point so that its window x is xw: x_ndc = 2*xw/W - 1 at z = 0 (w = 5)
+        t = np.tan(np.radians(30))
+        one[0, 0] = (2 * xw / W - 1) * 5 * t * (W / H)
+        cols = np.nonzero(np.any(oracle.splat(one, vp, W, H)[..., :3] != np.float32(0.8), axis=(0, 2)))[0].tolist()
+        assert cols == want, (xw, cols)
+
+
+def test_splat_order_independence_of_result(oracle):
+    """The final image depends on the point ORDER only through depth ties."""
+    W, H = 96, 64
+    vp = camera.perspective_vk(70, W / H) @ camera.look_at((1, 2, 6), (0, 0, 0))
+    pts = _cloud(5000, 3)
+    a = oracle.splat(pts, vp, W, H)
+    perm = np.random.default_rng(0).permutation(len(pts))
+    b = oracle.splat(pts[perm], vp, W, H)
+    assert (a != b).any(axis=2).mean() < 0.01   # only exact D24 ties may differ

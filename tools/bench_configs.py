@@ -98,5 +98,16 @@ ms = timeit(lambda: tr.post_dev(img.data_ptr(), n, 0, o8.data_ptr(), stream=s.cu
 print(f"{'post pass 4096^2 -> unorm8':34s} {'post':10s} {ms:8.4f} ms  {20 * n / ms / 1e6:7.0f} GB/s ({20 * n / ms / 8e9 * 100:4.1f}% of 8 TB/s, 20 B/px)")
 ms = timeit(lambda: tr.post_dev(img.data_ptr(), n, of.data_ptr(), 0, stream=s.cuda_stream))
 print(f"{'post pass 4096^2 -> f32':34s} {'post':10s} {ms:8.4f} ms  {32 * n / ms / 1e6:7.0f} GB/s ({32 * n / ms / 8e9 * 100:4.1f}% of 8 TB/s, 32 B/px)")
+# re-projection of a 4096x2048 capture (8.4 M points) into a 2048^2 view
+n = 4096 * 2048
+gen = torch.Generator(device=dev).manual_seed(2)
+cloud = torch.zeros(n, 8, device=dev)
+cloud[:, :3] = torch.rand(n, 3, device=dev, generator=gen) * 6 - 3
+cloud[:, 4:7] = torch.rand(n, 3, device=dev, generator=gen)
+vp = camera.perspective_vk(60, 1.0) @ camera.look_at((1.0, 2.0, 7.0), (0.0, 0.0, 0.0))
+img2 = torch.empty(2048, 2048, 4, device=dev)
+ms = timeit(lambda: tr.splat_dev(cloud.data_ptr(), n, vp, 2048, 2048, img2.data_ptr(), stream=s.cuda_stream))
+print(f"{'re-projection 8.4M pts -> 2048^2':34s} {'splat':10s} {ms:8.4f} ms  {n / ms / 1e6:7.2f} Gpoints/s  "
+      f"{(32 * n + 24 * 2048 * 2048) / ms / 1e6:7.0f} GB/s algorithmic (32 B/point + 24 B/pixel)")
 W = 8192
 render_case("C5 shape on ONE GPU: 8192^2", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W, variants=("listed",))

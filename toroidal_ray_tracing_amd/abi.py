@@ -71,6 +71,10 @@ class trt_hits(C.Structure):
                 ("nx", C.c_void_p), ("ny", C.c_void_p), ("nz", C.c_void_p), ("id", C.c_void_p)]
 
 
+class trt_point(C.Structure):
+    _fields_ = [("pos", C.c_float * 4), ("color", C.c_float * 4)]
+
+
 class trt_tiling(C.Structure):
     _fields_ = [("group_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32),
                 ("compact", C.c_uint32)]
@@ -83,7 +87,7 @@ class trt_stats(C.Structure):
 
 assert C.sizeof(trt_globals) == 204 and C.sizeof(trt_push) == 44
 assert C.sizeof(trt_material) == 80 and C.sizeof(trt_torus) == 24
-assert C.sizeof(trt_rendered_data) == 64
+assert C.sizeof(trt_rendered_data) == 64 and C.sizeof(trt_point) == 32
 
 HIT_FIELDS = ("t", "px", "py", "pz", "nx", "ny", "nz", "id")
 RAY_FIELDS = ("ox", "oy", "oz", "dx", "dy", "dz")

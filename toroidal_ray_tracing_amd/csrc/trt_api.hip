@@ -53,6 +53,7 @@ struct trt_ctx {
   // staging for the host-pointer entry points (grow-only, freed in trt_destroy)
   DevBuf d_in[6], d_out[8], d_rgba, d_rendered;
   DevBuf d_tiles;  // LIVE + CLEAR tile lists of the persistent kernel
+  DevBuf d_keys;   // depth|index keys of trt_splat_dev
 };
 
 namespace {
@@ -274,7 +275,7 @@ extern "C" void trt_destroy(trt_ctx* ctx)
   if(ctx->d_stats) (void)hipFree(ctx->d_stats);
   if(ctx->d_queue) (void)hipFree(ctx->d_queue);
   if(ctx->h_toro) (void)hipHostFree(ctx->h_toro);
-  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered, &ctx->d_tiles};
+  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered, &ctx->d_tiles, &ctx->d_keys};
   for(DevBuf* b : all)
     if(b->p) (void)hipFree(b->p);
   for(DevBuf& b : ctx->d_in)
@@ -575,5 +576,27 @@ extern "C" int trt_post_dev(trt_ctx* ctx, const float* rgba_in, uint64_t n_pixel
   TRT_HIP(ctx, hipSetDevice(ctx->device));
   ctx->last_stream = (hipStream_t)stream;
   TRT_HIP(ctx, launch_post(rgba_in, n_pixels, f32_out, unorm8_out, ctx->n_cus, (hipStream_t)stream));
+  return TRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// point-cloud re-projection
+// ------------------------------------------------------------------------------------------
+extern "C" int trt_splat_dev(trt_ctx* ctx, const trt_point* points, uint64_t n_points, const float* viewProj,
+                             uint32_t W, uint32_t H, const float* clearColor, float point_size, float* rgba,
+                             void* stream)
+{
+  if(!ctx) return TRT_E_INVALID;
+  if(!viewProj || !clearColor || !rgba || (n_points && !points))
+    return fail(ctx, TRT_E_INVALID, "trt_splat: NULL argument");
+  if(W == 0 || H == 0 || (uint64_t)W * H > 0x7fffffffull || n_points > 0xffffffffull)
+    return fail(ctx, TRT_E_INVALID, "trt_splat: bad sizes W=%u H=%u n_points=%llu", W, H, (unsigned long long)n_points);
+  if(!(point_size > 0.0f && point_size <= 64.0f))
+    return fail(ctx, TRT_E_INVALID, "trt_splat: point_size %g outside (0, 64]", (double)point_size);
+  TRT_HIP(ctx, hipSetDevice(ctx->device));
+  if(int rc = grow(ctx, ctx->d_keys, (size_t)W * H * sizeof(unsigned long long))) return rc;
+  ctx->last_stream = (hipStream_t)stream;
+  TRT_HIP(ctx, launch_splat(points, n_points, viewProj, W, H, clearColor, point_size,
+                            (unsigned long long*)ctx->d_keys.p, rgba, ctx->n_cus, (hipStream_t)stream));
   return TRT_OK;
 }

@@ -900,6 +900,93 @@ hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_
 }
 
 // ------------------------------------------------------------------------------------------
+// point-cloud re-projection (SEC/): z-buffered point splatting with 64-bit atomic keys
+// ------------------------------------------------------------------------------------------
+// key = depth24 << 32 | point index.  atomicMin over the keys of a pixel yields the smallest
+// depth and, among equal depths, the smallest index — exactly what in-order rasterisation
+// with depth test LESS produces.  A cleared pixel holds 0x00FFFFFF'00000000, which no fragment
+// can beat unless its depth is < 1.0 (LESS).  HBM-bound integer work: 32 B read per point,
+// 8-B atomics on its ≈6 pixels, one 8-B read + 16-B write per pixel in the resolve.
+constexpr unsigned long long kSplatClear = 0x00FFFFFFull << 32;
+
+__global__ __launch_bounds__(256) void splat_clear_kernel(unsigned long long* keys, uint64_t n)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    keys[i] = kSplatClear;
+}
+
+struct SplatArgs {
+  float    vp[16];
+  uint32_t W, H;
+  float    half;   // point_size / 2
+};
+
+__global__ __launch_bounds__(256) void splat_points_kernel(const trt_point* __restrict__ pts, uint64_t n, const SplatArgs a,
+                                                           unsigned long long* keys)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  {
+    const float4 p = reinterpret_cast<const float4*>(pts)[2 * i];
+    // gl_Position = uni.viewProj * vec4(position, 1.0)   (SEC vert_shader.vert:51)
+    const float cx = fma_(a.vp[12], 1.0f, fma_(a.vp[8], p.z, fma_(a.vp[4], p.y, a.vp[0] * p.x)));
+    const float cy = fma_(a.vp[13], 1.0f, fma_(a.vp[9], p.z, fma_(a.vp[5], p.y, a.vp[1] * p.x)));
+    const float cz = fma_(a.vp[14], 1.0f, fma_(a.vp[10], p.z, fma_(a.vp[6], p.y, a.vp[2] * p.x)));
+    const float cw = fma_(a.vp[15], 1.0f, fma_(a.vp[11], p.z, fma_(a.vp[7], p.y, a.vp[3] * p.x)));
+    if(!(cw > 0.0f && cx >= -cw && cx <= cw && cy >= -cw && cy <= cw && cz >= 0.0f && cz <= cw))
+      continue;  // point clipping: the vertex is outside the view volume (NaN lands here too)
+    const float iw = 1.0f / cw;
+    const float xf = fma_(cx * iw, 0.5f, 0.5f) * (float)a.W;
+    const float yf = fma_(cy * iw, 0.5f, 0.5f) * (float)a.H;
+    const uint32_t z24 = (uint32_t)rintf((cz * iw) * 16777215.0f);
+    const unsigned long long key = ((unsigned long long)z24 << 32) | (unsigned long long)(uint32_t)i;
+    // pixel centres c = j + 0.5 with lo <= c < hi  ⇔  j in [ceil(lo - 0.5), ceil(hi - 0.5))
+    const int x0 = max((int)ceilf(xf - a.half - 0.5f), 0), x1 = min((int)ceilf(xf + a.half - 0.5f), (int)a.W);
+    const int y0 = max((int)ceilf(yf - a.half - 0.5f), 0), y1 = min((int)ceilf(yf + a.half - 0.5f), (int)a.H);
+    for(int y = y0; y < y1; ++y)
+      for(int x = x0; x < x1; ++x)
+        atomicMin(&keys[(size_t)y * a.W + x], key);
+  }
+}
+
+__global__ __launch_bounds__(256) void splat_resolve_kernel(const unsigned long long* __restrict__ keys, uint64_t n,
+                                                            const trt_point* __restrict__ pts, float4 clear, float4* rgba)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  {
+    const unsigned long long k = keys[i];
+    float4 c = clear;
+    if(k != kSplatClear)
+    {
+      const float4 pc = reinterpret_cast<const float4*>(pts)[2 * (size_t)(uint32_t)k + 1];
+      c = make_float4(pc.x, pc.y, pc.z, 1.0f);   // o_color = vec4(current.color.xyz, 1.0)  (frag_shader.frag:44)
+    }
+    rgba[i] = c;
+  }
+}
+
+hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp, uint32_t W, uint32_t H,
+                        const float* clear, float point_size, unsigned long long* keys, float* rgba, int n_cus,
+                        hipStream_t stream)
+{
+  const uint64_t npx = (uint64_t)W * H, cap = (uint64_t)n_cus * 16;
+  auto grid = [&](uint64_t n) { const uint64_t w = (n + 255) / 256; return dim3((uint32_t)(w < cap ? (w ? w : 1) : cap)); };
+  hipLaunchKernelGGL(splat_clear_kernel, grid(npx), dim3(256), 0, stream, keys, npx);
+  if(n_points)
+  {
+    SplatArgs a;
+    for(int i = 0; i < 16; ++i) a.vp[i] = vp[i];
+    a.W = W; a.H = H; a.half = point_size * 0.5f;
+    hipLaunchKernelGGL(splat_points_kernel, grid(n_points), dim3(256), 0, stream, pts, n_points, a, keys);
+  }
+  hipLaunchKernelGGL(splat_resolve_kernel, grid(npx), dim3(256), 0, stream, keys, npx, pts,
+                     make_float4(clear[0], clear[1], clear[2], clear[3]), reinterpret_cast<float4*>(rgba));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream)

@@ -49,6 +49,9 @@ enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1, kRenderListed = 2
 constexpr int kPersistentBlocksPerCU = 16;  // 4× the resident 4 blocks/CU: the dispatcher evens out the tile costs
 
 hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, hipStream_t stream);
+hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp, uint32_t W, uint32_t H,
+                        const float* clear, float point_size, unsigned long long* keys, float* rgba, int n_cus,
+                        hipStream_t stream);
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
                          hipStream_t stream);

@@ -36,6 +36,8 @@ SYMBOLS = {
                                        C.POINTER(abi.trt_hits), C.c_void_p, C.c_void_p]),
     "trt_tiling_rows": (C.c_uint32, [C.POINTER(abi.trt_tiling), C.c_uint32]),
     "trt_post_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trt_splat_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, abi.f32p, C.c_uint32, C.c_uint32, abi.f32p,
+                                C.c_float, C.c_void_p, C.c_void_p]),
     "trt_enable_stats": (C.c_int, [C.c_void_p, C.c_int]),
     "trt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(abi.trt_stats)]),
     "trt_set_render_variant": (C.c_int, [C.c_void_p, C.c_char_p]),

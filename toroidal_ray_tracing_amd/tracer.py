@@ -135,6 +135,16 @@ class Tracer:
                                          C.c_void_p(int(unorm8_out_ptr) or None),
                                          C.c_void_p(int(stream) or None)))
 
+    def splat_dev(self, points_ptr, n_points, view_proj, W, H, rgba_ptr, clear=(0.8, 0.8, 0.8, 1.0),
+                  point_size=2.5, stream=0):
+        """Point-cloud re-projection of ray_tracing__before_second (trt_splat_dev).  view_proj:
+        4x4 numpy matrix in math convention (M[row, col]); clear colour as SEC/main.cpp:178."""
+        vp = (C.c_float * 16)(*np.asarray(view_proj, np.float32).T.reshape(-1).tolist())
+        cc = (C.c_float * 4)(*[float(v) for v in clear])
+        self._check(self._L.trt_splat_dev(self._h, C.c_void_p(int(points_ptr) or None), int(n_points), vp, W, H,
+                                          cc, float(point_size), C.c_void_p(int(rgba_ptr) or None),
+                                          C.c_void_p(int(stream) or None)))
+
     def raytrace(self, scene, g, light, max_depth, clear_color, W, H, rgba_ptr, camera=0, rho=0.0,
                  **kw):
         """Mirror of ``HelloVulkan::raytrace(cmdBuf, clearColor)``: fills PushConstantRay from
