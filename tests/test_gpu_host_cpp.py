@@ -66,3 +66,23 @@ def test_toroidal_sweep_formats(tmp_path):
     g = (rho_hit - 14.0) ** 2 + pos[..., 1][hit] ** 2 - 9.0            # on the R=14, r=3 torus
     assert np.abs(g).max() < 2e-3                                      # 6 significant digits in the file
     assert np.all(col[~hit.T] == 0.8)                                  # misses: clear colour * 0.8
+
+
+def test_reproject_example_consumes_a_capture(tmp_path):
+    """toroidal_sweep writes captures; reproject (the SEC consumer) loads one with the
+    reference's text conventions ("x y z" lines, "-nan" -> lowest()) and rasterises it."""
+    sweep = os.path.join(ROOT, "examples", "toroidal_sweep")
+    reproj = os.path.join(ROOT, "examples", "reproject")
+    (tmp_path / "data").mkdir()
+    W = H = 64   # square: positions (x*H+y) and colours (row-major) are paired line by line
+    subprocess.run([sweep, str(tmp_path) + "/", str(W), str(H)], check=True, capture_output=True)
+    # inject the "-nan" convention of the reference's dumps into a few position lines
+    pos = tmp_path / "data" / "renderedPosition4.500000.txt"
+    lines = pos.read_text().splitlines()
+    lines[5] = "-nan(ind) -nan(ind) -nan(ind)"
+    lines[7] = "garbage"
+    pos.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([reproj, str(tmp_path) + "/", "4.500000", "128", "96"], check=True, capture_output=True,
+                         text=True).stdout
+    n_points, covered = int(out.split()[0]), int(out.split("pixels covered")[0].split(",")[-1])
+    assert n_points == W * H and 0 < covered < 128 * 96

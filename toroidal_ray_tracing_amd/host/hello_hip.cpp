@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <limits>
+#include <sstream>
 #include <stdexcept>
 
 namespace {
@@ -128,7 +130,9 @@ void HelloHip::destroyResources()
 {
   if(m_dColor) (void)hipFree(m_dColor);
   if(m_dRendered) (void)hipFree(m_dRendered);
-  m_dColor = nullptr; m_dRendered = nullptr;
+  if(m_dPost) (void)hipFree(m_dPost);
+  if(m_dCloud) (void)hipFree(m_dCloud);
+  m_dColor = nullptr; m_dRendered = nullptr; m_dPost = nullptr; m_dCloud = nullptr;
   if(m_ctx) trt_destroy(m_ctx);
   m_ctx = nullptr;
 }
@@ -207,4 +211,78 @@ void HelloHip::writeColorImage(const char* dir)
       const float* p = &m_hostColor[((size_t)y * m_size.width + x) * 4];
       outfile << p[0] << " " << p[1] << " " << p[2] << std::endl;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// post pass
+// ---------------------------------------------------------------------------------------------
+void HelloHip::drawPost(void* stream)
+{
+  const size_t n = (size_t)m_size.width * m_size.height;
+  if(!m_dPost) hipCheck(hipMalloc((void**)&m_dPost, n * 4), "hipMalloc(post)");
+  check(trt_post_dev(m_ctx, m_dColor, n, nullptr, m_dPost, stream), "HelloHip::drawPost");
+}
+
+void HelloHip::copyPostImage(void* stream)
+{
+  m_hostPost.resize((size_t)m_size.width * m_size.height * 4);
+  hipCheck(hipMemcpyAsync(m_hostPost.data(), m_dPost, m_hostPost.size(), hipMemcpyDeviceToHost, (hipStream_t)stream), "copyPostImage");
+  hipCheck(hipStreamSynchronize((hipStream_t)stream), "copyPostImage");
+}
+
+// ---------------------------------------------------------------------------------------------
+// point-cloud re-projection (ray_tracing__before_second)
+// ---------------------------------------------------------------------------------------------
+namespace {
+// one "x y z" text file -> vec3 list; "-nan" fields and unreadable lines become lowest()
+void loadVec3File(const std::string& filename, std::vector<std::array<float, 3>>& out)
+{
+  std::ifstream in(filename);
+  if(!in) throw std::runtime_error("loadPoints: cannot open " + filename);
+  const float low = std::numeric_limits<float>::lowest();
+  std::string line;
+  while(std::getline(in, line))
+  {
+    std::array<float, 3> v{low, low, low};
+    std::istringstream   iss(line);
+    std::string          f[3];
+    if(iss >> f[0] >> f[1] >> f[2])
+      for(int k = 0; k < 3; ++k)
+        v[k] = f[k].find("-nan") != std::string::npos ? low : std::stof(f[k]);
+    out.push_back(v);
+  }
+}
+}  // namespace
+
+void HelloHip::loadPoints(const std::string& positionFile, const std::string& colorFile)
+{
+  m_positions.clear();
+  m_colors.clear();
+  loadVec3File(positionFile, m_positions);
+  loadVec3File(colorFile, m_colors);
+}
+
+void HelloHip::createCloudDataBuffer()
+{
+  if(m_positions.size() != m_colors.size())
+    throw std::runtime_error("Number of positions and colors don't match!");   // SEC :636-639
+  m_cloudData.resize(m_positions.size());
+  for(size_t i = 0; i < m_positions.size(); ++i)
+    m_cloudData[i] = trt_point{{m_positions[i][0], m_positions[i][1], m_positions[i][2], 0.f},
+                               {m_colors[i][0], m_colors[i][1], m_colors[i][2], 0.f}};   // vec4(…, 0), :646-647
+  if(m_dCloud) hipCheck(hipFree(m_dCloud), "hipFree");
+  m_dCloud = nullptr;
+  if(!m_cloudData.empty())
+  {
+    hipCheck(hipMalloc((void**)&m_dCloud, m_cloudData.size() * sizeof(trt_point)), "hipMalloc(cloud)");
+    hipCheck(hipMemcpy(m_dCloud, m_cloudData.data(), m_cloudData.size() * sizeof(trt_point), hipMemcpyHostToDevice), "upload cloud");
+  }
+}
+
+void HelloHip::rasterize(void* stream, const std::array<float, 4>& clearColor)
+{
+  // vkCmdDraw(numPoints, 1, 0, 0) on the POINT_LIST pipeline, gl_PointSize = 2.5 (SEC :313-330)
+  check(trt_splat_dev(m_ctx, m_dCloud, m_cloudData.size(), m_globals.viewProj, m_size.width, m_size.height,
+                      clearColor.data(), 2.5f, m_dColor, stream),
+        "HelloHip::rasterize");
 }

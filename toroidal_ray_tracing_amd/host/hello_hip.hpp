@@ -57,6 +57,18 @@ public:
   void writeRenderedRays(const char* dir);      // dir + "data/origins.txt", "data/directions.txt"
   void writeColorImage(const char* dir);        // dir + "data/renderedColor<rho>.txt": row-major "r g b\n"
 
+  // --- post pass (drawPost, ray_tracing_reflections/hello_vulkan.cpp:560-579 + post.frag) ------
+  void drawPost(void* stream);              // tonemap m_dColor -> 8-bit image (pow(c, 1/2.2))
+  void copyPostImage(void* stream);         // device -> host
+  const std::vector<uint8_t>& postImage() const { return m_hostPost; }
+
+  // --- point-cloud re-projection (ray_tracing__before_second) -------------------------------
+  // loadPoints (SEC/hello_vulkan.cpp:496-628): "x y z" per line, "-nan" -> numeric_limits<float>::lowest()
+  void loadPoints(const std::string& positionFile, const std::string& colorFile);
+  void createCloudDataBuffer();             // :633-660 — throws if the two files disagree in length
+  void rasterize(void* stream, const std::array<float, 4>& clearColor);  // :313-330, POINT_LIST draw into m_dColor
+  size_t numPoints() const { return m_cloudData.size(); }
+
   // --- state, named as in the reference -----------------------------------------------------
   PushConstantRaster m_pcRaster;
   trt_push           m_pcRay{{0, 0, 0, 0}, {0, 0, 0}, 0.f, 0, 10, 0.f};  // maxDepth 10 (hello_vulkan.h:157)
@@ -81,4 +93,9 @@ private:
   trt_rendered_data*         m_dRendered{nullptr};
   std::vector<float>             m_hostColor;
   std::vector<trt_rendered_data> m_hostRendered;
+  uint8_t*                       m_dPost{nullptr};
+  std::vector<uint8_t>           m_hostPost;
+  std::vector<std::array<float, 3>> m_positions, m_colors;   // SEC: m_positions / m_colors
+  std::vector<trt_point>         m_cloudData;                // SEC: m_cloudData
+  trt_point*                     m_dCloud{nullptr};
 };
