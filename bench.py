@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--variant", default=None, help="render kernel variant (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hits", default="tpn", choices=["tpn", "none"], help="first-hit record streams to write")
+    ap.add_argument("--gather", default="fp32", choices=["fp32", "rgba8", "none"],
+                    help="N>1: what is all-gathered after each frame (default: the rgba32f framebuffer)")
     ap.add_argument("--center", default="0,0,0", help="camera look-at point (diagnostics; default = BASELINE)")
     return ap.parse_args()
 
@@ -115,7 +117,8 @@ def main():
         tr.set_render_variant(a.variant)
     variant = tr.render_variant()
 
-    frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else ())
+    frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else (),
+                            gather=a.gather)
     stream = torch.cuda.current_stream()
 
     def step(ev=None):

@@ -72,6 +72,12 @@ class _OracleTracer:
             local[k:k + G] = band[y0:y0 + G]
         ctypes.memmove(rgba_ptr, local.ctypes.data, local.nbytes)
 
+    def post_dev(self, rgba_ptr, n_pixels, f32_out_ptr=0, unorm8_out_ptr=0, stream=0):
+        import ctypes
+        src = np.ctypeslib.as_array(ctypes.cast(rgba_ptr, ctypes.POINTER(ctypes.c_float)), shape=(n_pixels, 4))
+        _, u8 = self.oracle.post(src)
+        ctypes.memmove(unorm8_out_ptr, u8.ctypes.data, u8.nbytes)
+
 
 class _Stream:
     cuda_stream = 0
@@ -93,9 +99,15 @@ def _worker(rank, world, port, W, H, G, out):
         for depth in (1, 2, 3):
             frame.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
         full = frame.finish().clone()
+        # the 8-bit gather mode: tonemapped rows, same pipeline
+        frame8 = trtd.TiledFrame(tr, W, H, world, rank, torch.device("cpu"), group_rows=G, gather="rgba8")
+        for depth in (2, 3):
+            frame8.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
+        full8 = frame8.finish().clone()
         if rank == 0:
             want, _, _, _ = tr.oracle.render(sc, g, camera.baseline_push(3), W, H, want_hits=False)
             ok = bool(np.array_equal(full.numpy(), want))
+            ok = ok and full8.dtype == torch.uint8 and bool(np.array_equal(full8.numpy(), tr.oracle.post(want)[1]))
             out.put(ok)
         dist.barrier()
     finally:

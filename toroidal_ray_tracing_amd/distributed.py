@@ -47,8 +47,16 @@ class TiledFrame:
 
     def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=DEFAULT_GROUP_ROWS,
                  gather=True):
+        """gather: True / "fp32" — all-gather the rgba32f framebuffer (default, what north_star
+        prescribes); "rgba8" — tonemap each rank's rows (trt_post_dev, post.frag) and all-gather
+        the 8-bit image a swapchain would present: 4x fewer bytes over xGMI, the rgba32f image
+        stays sharded; False / "none" — no collective."""
         self.tr, self.W, self.H, self.world, self.rank = tracer, W, H, world, rank
-        self.group_rows, self.gather = group_rows, gather and world > 1
+        mode = {True: "fp32", False: "none"}.get(gather, gather)
+        if mode not in ("fp32", "rgba8", "none"):
+            raise ValueError(f"gather={gather!r}")
+        self.mode = mode if world > 1 else "none"
+        self.group_rows, self.gather = group_rows, self.mode != "none"
         if world > 1 and H % (group_rows * world) != 0:
             raise ValueError(f"H={H} must be a multiple of group_rows*world={group_rows * world}")
         self.tiling = abi.trt_tiling(group_rows, world, rank, 1 if world > 1 else 0)
@@ -61,8 +69,10 @@ class TiledFrame:
         if "id" in want_hits:
             self.hits["id"] = torch.empty(self.local_pixels, dtype=torch.int32, device=device)
         # concatenated along dim 0 (the form both RCCL and gloo accept); viewed as [N, H/N, W, 4]
-        self.gathered = [torch.empty(world * self.local_rows, W, 4, **f32) for _ in range(nbuf)] if self.gather else None
-        self.full = torch.empty(H, W, 4, **f32) if self.gather else self.locals[0]
+        gdt = dict(dtype=torch.uint8 if self.mode == "rgba8" else torch.float32, device=device)
+        self.sends = [torch.empty(self.local_rows, W, 4, **gdt) for _ in range(nbuf)] if self.mode == "rgba8" else self.locals
+        self.gathered = [torch.empty(world * self.local_rows, W, 4, **gdt) for _ in range(nbuf)] if self.gather else None
+        self.full = torch.empty(H, W, 4, **gdt) if self.gather else self.locals[0]
         self._pending = [None] * nbuf   # in-flight all-gather of each buffer set
         self._k = 0
 
@@ -73,8 +83,9 @@ class TiledFrame:
     def describe(self):
         if self.world == 1:
             return "single GPU, full frame"
+        what = {"fp32": "all_gather_into_tensor(rgba32f)", "rgba8": "post pass + all_gather_into_tensor(rgba8)"}.get(self.mode)
         return (f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; "
-                f"{'all_gather_into_tensor(rgba32f) pipelined behind the next frame + de-interleave' if self.gather else 'no gather'}")
+                f"{what + ' pipelined behind the next frame + de-interleave' if self.gather else 'no gather'}")
 
     def _retire(self, b):
         """Wait for the gather of buffer set b and assemble its frame."""
@@ -102,8 +113,11 @@ class TiledFrame:
                                      camera=camera, hit_ptrs=hp, stream=stream.cuda_stream)
         if events:
             events[1].record(stream)
+        if self.mode == "rgba8":
+            self.tr.post_dev(self.locals[b].data_ptr(), self.local_pixels, 0, self.sends[b].data_ptr(),
+                             stream=stream.cuda_stream)
         if self.gather:
-            self._pending[b] = dist.all_gather_into_tensor(self.gathered[b], self.locals[b], async_op=True)
+            self._pending[b] = dist.all_gather_into_tensor(self.gathered[b], self.sends[b], async_op=True)
         return self.full
 
     def finish(self):
