@@ -488,8 +488,14 @@ enum : int { K_NONE = 0, K_CLOSEST = 1, K_SHADOW = 2 };
 // writer on this chip: a dword store of 8×32-B row pieces is issue-limited to ≈3 B/clk/CU.)
 __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t packed, uint32_t lane)
 {
+  // The constants of the miss record are (re)materialised HERE on purpose: hoisted out of the
+  // caller's tile loop they stay live across the whole solve, get spilled to scratch, and every
+  // reload is a vector-memory load whose s_waitcnt drains the stream of output stores.
   // (clearColor·0.8, 1): rmiss:37 → rgen:76 with attenuation 1 and hitValue 0 → rgen:87
-  const float4 c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, 1.0f);
+  const volatile float* cc = a.pc.clearColor;
+  const float4 c = make_float4(cc[0] * 0.8f, cc[1] * 0.8f, cc[2] * 0.8f, 1.0f);
+  float inf, zero;
+  asm volatile("v_mov_b32 %0, 0x7f800000\n\tv_mov_b32 %1, 0" : "=v"(inf), "=v"(zero));
   const uint32_t x0 = (packed & 0xffffu) * 8, ly = (packed >> 16) * 8 + (lane >> 3), q = lane & 7;
   if(ly >= a.n_local_rows)
     return 0;
@@ -511,8 +517,7 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
   const uint32_t xs = x0 + 4 * q;
   if(a.vec4_ok && xs + 3 < a.W)
   {
-    const float  inf = __builtin_inff();
-    const float4 tv = make_float4(inf, inf, inf, inf), zv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 tv = make_float4(inf, inf, inf, inf), zv = make_float4(zero, zero, zero, zero);
     const size_t i = row + xs;
     if(a.hits.t) *reinterpret_cast<float4*>(a.hits.t + i) = tv;
     if(a.hits.px) *reinterpret_cast<float4*>(a.hits.px + i) = zv;
@@ -527,7 +532,7 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
   {
     for(uint32_t k = 0; k < 4; ++k)
       if(xs + k < a.W)
-        store_first_hit(a, row + xs + k, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);
+        store_first_hit(a, row + xs + k, inf, {zero, zero, zero}, {zero, zero, zero}, -1);
   }
   return n;
 }
@@ -812,9 +817,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 // hardware workgroup dispatcher balances the (very uneven) tile costs; the clear stores of
 // blocks that finish early overlap the solve of the others.
 #ifndef TRT_LISTED_WAVES
-#define TRT_LISTED_WAVES 4
+#define TRT_LISTED_WAVES 5
 #endif
-template <class Real>
+template <class Real, bool STATS>
 __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
 {
   __shared__ SceneK     S;
@@ -847,17 +852,21 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
       clear_cache = i + lane < my_clear ? a.tiles_clear[g_wave + (size_t)(i + lane) * n_waves] : 0u;
       settle_loads(live_cache, clear_cache);
     }
+    // lane-derived values (lane & 7, lane >> 3, …) are recomputed per trip from an opaque copy:
+    // hoisted out of the loop they would be spilled, and a spill reload is a vector-memory load
+    uint32_t ln = lane;
+    asm volatile("" : "+v"(ln));
     if(i < my_clear && !(a.debug_skip & 1u))
-      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane) * (uint32_t)S.n_tori;
+      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), ln) * (uint32_t)S.n_tori;
     if(i < my_live && !(a.debug_skip & 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
-      const uint32_t x = (packed & 0xffffu) * 8 + (lane & 7), ly = (packed >> 16) * 8 + (lane >> 3);
+      const uint32_t x = (packed & 0xffffu) * 8 + (ln & 7), ly = (packed >> 16) * 8 + (ln >> 3);
       if(x < a.W && ly < a.n_local_rows)
         trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
     }
   }
-  if(a.stats)
+  if(STATS && a.stats)   // STATS = false: the three counters are dead code (3 VGPRs and their increments)
   {
     wave_add(&a.stats[0], n_primary);
     wave_add(&a.stats[1], n_bounce);
@@ -1026,9 +1035,15 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       const uint32_t wpb = bthreads / 64;
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
       if(scene.f64)
-        hipLaunchKernelGGL(render_listed_kernel<double>, dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
+      {
+        if(a.stats) hipLaunchKernelGGL((render_listed_kernel<double, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
+        else hipLaunchKernelGGL((render_listed_kernel<double, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
+      }
       else
-        hipLaunchKernelGGL(render_listed_kernel<float>, dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
+      {
+        if(a.stats) hipLaunchKernelGGL((render_listed_kernel<float, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
+        else hipLaunchKernelGGL((render_listed_kernel<float, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
+      }
       return hipGetLastError();
     }
     const uint32_t grid = (uint32_t)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);
