@@ -21,6 +21,22 @@
 namespace trt {
 
 // ------------------------------------------------------------------------------------------
+// global-memory accessors
+// ------------------------------------------------------------------------------------------
+// The long kernels read their arguments (and thus their output POINTERS) from LDS, so hipcc no
+// longer knows that those pointers address global memory and would emit flat_load/flat_store —
+// slower, and counted on lgkmcnt as well, so that every LDS wait would also wait for them.
+// These helpers cast to the global address space: global_load / global_store.
+template <class T> using gptr = __attribute__((address_space(1))) T*;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int   i4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st1(float* base, size_t i, float v) { ((gptr<float>)base)[i] = v; }
+__device__ __forceinline__ void st1(int32_t* base, size_t i, int32_t v) { ((gptr<int32_t>)base)[i] = v; }
+__device__ __forceinline__ void st4(float* p, float4 v) { *((gptr<f4v>)p) = f4v{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st4(int32_t* p, int x, int y, int z, int w) { *((gptr<i4v>)p) = i4v{x, y, z, w}; }
+__device__ __forceinline__ uint32_t ld1(const uint32_t* base, size_t i) { return ((gptr<const uint32_t>)base)[i]; }
+
+// ------------------------------------------------------------------------------------------
 // closest-hit shader body, split at the shadow query (REFL/shaders/raytrace.rchit:50-156)
 // ------------------------------------------------------------------------------------------
 struct HitState {
@@ -96,16 +112,22 @@ __device__ __forceinline__ size_t out_index(const RenderArgs& a, uint32_t x, uin
   return (size_t)(a.compact ? ly : y) * a.W + x;
 }
 
-__device__ __forceinline__ void store_first_hit(const RenderArgs& a, size_t i, float t, v3 P, v3 N, int id)
+__device__ __forceinline__ void store_first_hit(const RenderArgs& a, size_t i_, float t, v3 P, v3 N, int id)
 {
-  if(a.hits.t) a.hits.t[i] = t;
-  if(a.hits.px) a.hits.px[i] = P.x;
-  if(a.hits.py) a.hits.py[i] = P.y;
-  if(a.hits.pz) a.hits.pz[i] = P.z;
-  if(a.hits.nx) a.hits.nx[i] = N.x;
-  if(a.hits.ny) a.hits.ny[i] = N.y;
-  if(a.hits.nz) a.hits.nz[i] = N.z;
-  if(a.hits.id) a.hits.id[i] = id;
+  // The pixel index passes through an opaque copy so that the eight stream addresses are formed
+  // HERE, at the store, and not at the top of the pixel's bounce loop — where they would sit in
+  // 16 VGPRs across the whole solve (and get spilled).  W·H < 2³¹ (trt_render checks it).
+  uint32_t i32 = (uint32_t)i_;
+  asm volatile("" : "+v"(i32));
+  const size_t i = i32;
+  if(a.hits.t) st1(a.hits.t, i, t);
+  if(a.hits.px) st1(a.hits.px, i, P.x);
+  if(a.hits.py) st1(a.hits.py, i, P.y);
+  if(a.hits.pz) st1(a.hits.pz, i, P.z);
+  if(a.hits.nx) st1(a.hits.nx, i, N.x);
+  if(a.hits.ny) st1(a.hits.ny, i, N.y);
+  if(a.hits.nz) st1(a.hits.nz, i, N.z);
+  if(a.hits.id) st1(a.hits.id, i, id);
 }
 
 // wave-level sum of a 32-bit counter, then one atomic per wave
@@ -191,11 +213,11 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
   const size_t oi = out_index(a, x, y, ly);
   v3 origin, direction;
   raygen(a.g, a.toro, a.W, a.H, a.camera, x, y, origin, direction);
-  float4* rd = a.rendered ? reinterpret_cast<float4*>(&a.rendered[(size_t)x * a.H + y]) : nullptr;  // BEF rgen:72
+  float* rd = a.rendered ? reinterpret_cast<float*>(&a.rendered[(size_t)x * a.H + y]) : nullptr;  // BEF rgen:72
   if(rd)
   {
-    rd[2] = make_float4(origin.x, origin.y, origin.z, 1.0f);               // BEF rgen:56,72
-    rd[3] = make_float4(direction.x, direction.y, direction.z, 0.0f);      // BEF rgen:57,73
+    st4(rd + 8, make_float4(origin.x, origin.y, origin.z, 1.0f));            // BEF rgen:56,72
+    st4(rd + 12, make_float4(direction.x, direction.y, direction.z, 0.0f));  // BEF rgen:57,73
   }
 
   int depth = 0, done = 1;                                                 // rgen:54,57
@@ -212,7 +234,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
       if(depth == 0)
       {
         store_first_hit(a, oi, t, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);  // BEF rmiss:21
-        if(rd) rd[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if(rd) st4(rd, make_float4(0.0f, 0.0f, 0.0f, 1.0f));
       }
     }
     else
@@ -222,7 +244,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
       if(depth == 0)                                                       // BEF rgen:94-97
       {
         store_first_hit(a, oi, t, h.P, h.N, id);
-        if(rd) rd[0] = make_float4(h.P.x, h.P.y, h.P.z, 1.0f);             // BEF rgen:112
+        if(rd) st4(rd, make_float4(h.P.x, h.P.y, h.P.z, 1.0f));            // BEF rgen:112
       }
       bool shadowed = false;
       if(h.wantShadow)
@@ -240,8 +262,8 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
     done      = 1;                                                         // rgen:84
   }
   const float4 c = make_float4(hitValue.x, hitValue.y, hitValue.z, 1.0f);
-  if(a.rgba) reinterpret_cast<float4*>(a.rgba)[oi] = c;                    // rgen:87
-  if(rd) rd[1] = c;                                                        // BEF rgen:111
+  if(a.rgba) st4(a.rgba + 4 * oi, c);                                      // rgen:87
+  if(rd) st4(rd + 4, c);                                                   // BEF rgen:111
 }
 
 template <class Real, int TW>
@@ -492,10 +514,9 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
   // caller's tile loop they stay live across the whole solve, get spilled to scratch, and every
   // reload is a vector-memory load whose s_waitcnt drains the stream of output stores.
   // (clearColor·0.8, 1): rmiss:37 → rgen:76 with attenuation 1 and hitValue 0 → rgen:87
-  const volatile float* cc = a.pc.clearColor;
-  const float4 c = make_float4(cc[0] * 0.8f, cc[1] * 0.8f, cc[2] * 0.8f, 1.0f);
-  float inf, zero;
-  asm volatile("v_mov_b32 %0, 0x7f800000\n\tv_mov_b32 %1, 0" : "=v"(inf), "=v"(zero));
+  float inf, zero, one;
+  asm volatile("v_mov_b32 %0, 0x7f800000\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 1.0" : "=v"(inf), "=v"(zero), "=v"(one));
+  const float4 c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, one);
   const uint32_t x0 = (packed & 0xffffu) * 8, ly = (packed >> 16) * 8 + (lane >> 3), q = lane & 7;
   if(ly >= a.n_local_rows)
     return 0;
@@ -509,7 +530,7 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
     const uint32_t x = x0 + 8 * j + q;
     if(x < a.W)
     {
-      if(a.rgba) reinterpret_cast<float4*>(a.rgba)[row + x] = c;
+      if(a.rgba) st4(a.rgba + 4 * (row + x), c);
       ++n;
     }
   }
@@ -519,14 +540,14 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
   {
     const float4 tv = make_float4(inf, inf, inf, inf), zv = make_float4(zero, zero, zero, zero);
     const size_t i = row + xs;
-    if(a.hits.t) *reinterpret_cast<float4*>(a.hits.t + i) = tv;
-    if(a.hits.px) *reinterpret_cast<float4*>(a.hits.px + i) = zv;
-    if(a.hits.py) *reinterpret_cast<float4*>(a.hits.py + i) = zv;
-    if(a.hits.pz) *reinterpret_cast<float4*>(a.hits.pz + i) = zv;
-    if(a.hits.nx) *reinterpret_cast<float4*>(a.hits.nx + i) = zv;
-    if(a.hits.ny) *reinterpret_cast<float4*>(a.hits.ny + i) = zv;
-    if(a.hits.nz) *reinterpret_cast<float4*>(a.hits.nz + i) = zv;
-    if(a.hits.id) *reinterpret_cast<int4*>(a.hits.id + i) = make_int4(-1, -1, -1, -1);
+    if(a.hits.t) st4(a.hits.t + i, tv);
+    if(a.hits.px) st4(a.hits.px + i, zv);
+    if(a.hits.py) st4(a.hits.py + i, zv);
+    if(a.hits.pz) st4(a.hits.pz + i, zv);
+    if(a.hits.nx) st4(a.hits.nx + i, zv);
+    if(a.hits.ny) st4(a.hits.ny + i, zv);
+    if(a.hits.nz) st4(a.hits.nz + i, zv);
+    if(a.hits.id) st4(a.hits.id + i, -1, -1, -1, -1);
   }
   else
   {
@@ -550,9 +571,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   const int      n_tori  = S.n_tori;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(a.queue[0]);
-  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(a.queue[2]);
-  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
+  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
+  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)2));
+  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)1));
 
   // Queue state.  Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k caches the
   // wave's k-th entry of the current batch of 64 (one gather load per 64 tiles) and entries
@@ -561,8 +582,8 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   const uint32_t my_live_n  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;   // entries owned
   const uint32_t my_clear_n = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
   uint32_t k_live = 0, k_clear = 0;  // next owned entry (wave-uniform)
-  uint32_t live_cache  = lane < my_live_n ? a.tiles_live[live_slot(a, g_wave + lane * n_waves, n_heavy)] : 0u;
-  uint32_t clear_cache = lane < my_clear_n ? a.tiles_clear[g_wave + (size_t)lane * n_waves] : 0u;
+  uint32_t live_cache  = lane < my_live_n ? ld1(a.tiles_live, (size_t)live_slot(a, g_wave + lane * n_waves, n_heavy)) : 0u;
+  uint32_t clear_cache = lane < my_clear_n ? ld1(a.tiles_clear, g_wave + (size_t)lane * n_waves) : 0u;
   settle_loads(live_cache, clear_cache);
   bool     exhausted = my_live_n == 0;
   uint32_t cur = __builtin_amdgcn_readlane(live_cache, 0);
@@ -600,7 +621,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
     {
       if((k_clear & 63u) == 0 && k_clear)
       {
-        clear_cache = k_clear + lane < my_clear_n ? a.tiles_clear[g_wave + (size_t)(k_clear + lane) * n_waves] : 0u;
+        clear_cache = k_clear + lane < my_clear_n ? ld1(a.tiles_clear, g_wave + (size_t)(k_clear + lane) * n_waves) : 0u;
         settle_loads(live_cache, clear_cache);
       }
       const uint32_t packed = __builtin_amdgcn_readlane(clear_cache, k_clear & 63u);
@@ -626,7 +647,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         v3   prdHit = {0.0f, 0.0f, 0.0f};
         if(stage && kind == K_CLOSEST)
         {
-          float4* rd = a.rendered ? reinterpret_cast<float4*>(&a.rendered[(size_t)px * a.H + py]) : nullptr;
+          float* rd = a.rendered ? reinterpret_cast<float*>(&a.rendered[(size_t)px * a.H + py]) : nullptr;
           if(best_id < 0)
           {
             // miss shader (REFL rmiss:37; BEF rmiss:21 hitPosition = 0)
@@ -635,7 +656,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
             if(depth == 0)
             {
               store_first_hit(a, oi, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);
-              if(rd) rd[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+              if(rd) st4(rd, make_float4(0.0f, 0.0f, 0.0f, 1.0f));
             }
           }
           else
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
             if(depth == 0)                                                   // BEF rgen:94-97
             {
               store_first_hit(a, oi, best_t, h.P, h.N, best_id);
-              if(rd) rd[0] = make_float4(h.P.x, h.P.y, h.P.z, 1.0f);
+              if(rd) st4(rd, make_float4(h.P.x, h.P.y, h.P.z, 1.0f));
             }
             dir_in = qd;
             hN = h.N; hDiffuse = h.diffuse; hLightI = h.lightIntensity; hMat = h.matId;
@@ -685,8 +706,8 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
           if(done == 1 || depth >= a.pc.maxDepth)                            // rgen:79
           {
             const float4 c = make_float4(hitValue.x, hitValue.y, hitValue.z, 1.0f);
-            if(a.rgba) reinterpret_cast<float4*>(a.rgba)[oi] = c;            // rgen:87
-            if(a.rendered) reinterpret_cast<float4*>(&a.rendered[(size_t)px * a.H + py])[1] = c;
+            if(a.rgba) st4(a.rgba + 4 * oi, c);                              // rgen:87
+            if(a.rendered) st4(reinterpret_cast<float*>(&a.rendered[(size_t)px * a.H + py]) + 4, c);
             kind = K_NONE;
           }
           else
@@ -723,9 +744,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
             raygen(a.g, a.toro, a.W, a.H, a.camera, px, py, qo, qd);
             if(a.rendered)
             {
-              float4* rd = reinterpret_cast<float4*>(&a.rendered[(size_t)px * a.H + py]);
-              rd[2] = make_float4(qo.x, qo.y, qo.z, 1.0f);
-              rd[3] = make_float4(qd.x, qd.y, qd.z, 0.0f);
+              float* rd = reinterpret_cast<float*>(&a.rendered[(size_t)px * a.H + py]);
+              st4(rd + 8, make_float4(qo.x, qo.y, qo.z, 1.0f));
+              st4(rd + 12, make_float4(qd.x, qd.y, qd.z, 0.0f));
             }
             depth = 0; done = 1;
             attenuation = {1.0f, 1.0f, 1.0f};
@@ -745,7 +766,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
           {
             if((k_live & 63u) == 0)
             {
-              live_cache = k_live + lane < my_live_n ? a.tiles_live[live_slot(a, g_wave + (k_live + lane) * n_waves, n_heavy)] : 0u;
+              live_cache = k_live + lane < my_live_n ? ld1(a.tiles_live, (size_t)live_slot(a, g_wave + (k_live + lane) * n_waves, n_heavy)) : 0u;
               settle_loads(live_cache, clear_cache);
             }
             cur = __builtin_amdgcn_readlane(live_cache, k_live & 63u);
@@ -830,9 +851,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   const uint32_t lane    = threadIdx.x & 63;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(a.queue[0]);
-  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(a.queue[2]);
-  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(a.queue[1]);
+  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
+  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)2));
+  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)1));
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
 
   // Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k prefetches the wave's k-th
@@ -848,8 +869,8 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   {
     if((i & 63u) == 0)
     {
-      live_cache  = i + lane < my_live ? a.tiles_live[live_slot(a, g_wave + (i + lane) * n_waves, n_heavy)] : 0u;
-      clear_cache = i + lane < my_clear ? a.tiles_clear[g_wave + (size_t)(i + lane) * n_waves] : 0u;
+      live_cache  = i + lane < my_live ? ld1(a.tiles_live, (size_t)live_slot(a, g_wave + (i + lane) * n_waves, n_heavy)) : 0u;
+      clear_cache = i + lane < my_clear ? ld1(a.tiles_clear, g_wave + (size_t)(i + lane) * n_waves) : 0u;
       settle_loads(live_cache, clear_cache);
     }
     // lane-derived values (lane & 7, lane >> 3, …) are recomputed per trip from an opaque copy:
