@@ -95,15 +95,24 @@ struct SceneK {
   MaterialK      mat[TRT_MAX_MATERIALS];
 };
 
-// Copy the scene constants from the kernel-argument segment into LDS, one dword per thread
-// per trip.  Reads in the hot loops then hit LDS at wave-uniform (broadcast) or
-// material-indexed addresses.
+// Copy the scene constants from the kernel-argument segment into LDS — only the records in use
+// (n_tori solver records of the active precision, n_tori shading records, n_mat materials):
+// 30 dwords for one FP32 torus instead of the 372 of the full struct, one load per thread.
+// Reads in the hot loops then hit LDS at wave-uniform (broadcast) or material-indexed addresses.
 __device__ __forceinline__ void stage_scene(SceneK* lds, const SceneK& arg)
 {
+  static_assert(sizeof(SceneK) == 4 * (4 + 80 + 160 + 40 + 88) && sizeof(TorusK<float>) == 40 && sizeof(TorusShade) == 20
+                    && sizeof(MaterialK) == 44, "SceneK layout");
   const uint32_t* src = reinterpret_cast<const uint32_t*>(&arg);
   uint32_t*       dst = reinterpret_cast<uint32_t*>(lds);
-  for(uint32_t i = threadIdx.x; i < sizeof(SceneK) / 4; i += blockDim.x)
-    dst[i] = src[i];
+  const uint32_t  n = (uint32_t)arg.n_tori, nm = (uint32_t)arg.n_mat;
+  const uint32_t  c0 = 4, c1 = c0 + (arg.f64 ? 0u : 10u * n), c2 = c1 + (arg.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
+                 c4 = c3 + 11u * nm;
+  for(uint32_t i = threadIdx.x; i < c4; i += blockDim.x)
+  {
+    const uint32_t off = i < c0 ? i : i < c1 ? 4u + (i - c0) : i < c2 ? 84u + (i - c1) : i < c3 ? 244u + (i - c2) : 284u + (i - c3);
+    dst[off] = src[off];
+  }
   __syncthreads();
 }
 

@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
     // hoisted out of the loop they would be spilled, and a spill reload is a vector-memory load
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
-    if(i < my_clear && !(a.debug_skip & 1u))
+    if(i < my_clear && !(a.debug_skip & 1u) && !(a.debug_skip & 4u))
       n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), ln) * (uint32_t)S.n_tori;
     if(i < my_live && !(a.debug_skip & 2u))
     {
@@ -887,6 +887,16 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
         trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
     }
   }
+  if(a.debug_skip & 4u)   // experiment: all clear tiles after the traced ones
+    for(uint32_t i = 0; i < my_clear; ++i)
+    {
+      if((i & 63u) == 0)
+      {
+        clear_cache = i + lane < my_clear ? ld1(a.tiles_clear, g_wave + (size_t)(i + lane) * n_waves) : 0u;
+        settle_loads(live_cache, clear_cache);
+      }
+      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane) * (uint32_t)S.n_tori;
+    }
   if(STATS && a.stats)   // STATS = false: the three counters are dead code (3 VGPRs and their increments)
   {
     wave_add(&a.stats[0], n_primary);
@@ -1049,7 +1059,11 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
     if(const char* e = getenv("TRT_PERSIST_BLOCKS")) cap = (uint64_t)atoll(e);
     if(v == kRenderListed)
     {
-      uint64_t lcap = (uint64_t)n_cus * 32;  // oversubscribed: the dispatcher balances the tile costs
+      // one wave per 16 tiles (4096²: 16,384 blocks = 64 per CU): with ≈16 % of the tiles LIVE a
+      // wave traces at most one tile and writes ≈1 clear macro tile, so the dispatcher balances
+      // single tiles and compute/store phases of different blocks interleave on every CU
+      // (measured optimum at 2048², 4096² and 8192²; 8,192 blocks cost +25 % at 4096²)
+      uint64_t lcap = tiles / 16 > (uint64_t)n_cus * 4 ? tiles / 16 : (uint64_t)n_cus * 4;
       if(const char* e = getenv("TRT_LISTED_BLOCKS")) lcap = (uint64_t)atoll(e);
       uint32_t bthreads = 256;
       if(const char* e = getenv("TRT_LISTED_THREADS")) bthreads = (uint32_t)atoi(e);
