@@ -470,13 +470,11 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     if(int rc = grow(ctx, ctx->d_tiles, 2 * n_tiles * sizeof(uint32_t))) return rc;
     a.tiles_live  = (uint32_t*)ctx->d_tiles.p;
     a.tiles_clear = a.tiles_live + n_tiles;
-    a.tiles_cap   = (uint32_t)n_tiles;
     // tile culling needs tiles that are 8 contiguous image rows, and no per-pixel ray export
     a.tile_cull = (rendered == nullptr && (a.tile_parts <= 1 || a.tile_group % 8 == 0)) ? 1u : 0u;
     a.min_batch = 24;
     if(const char* e = getenv("TRT_MIN_BATCH")) a.min_batch = (uint32_t)atoi(e);
     if(getenv("TRT_NO_TILE_CULL")) a.tile_cull = 0;
-    a.tile_sort = (a.tile_cull && getenv("TRT_TILE_SORT")) ? 1u : 0u;
     if(const char* e = getenv("TRT_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(e);  // timing ablations only
     uintptr_t bits = 0;
     const void* hp[8] = {a.hits.t, a.hits.px, a.hits.py, a.hits.pz, a.hits.nx, a.hits.ny, a.hits.nz, a.hits.id};
@@ -490,10 +488,10 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
   TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
   if(ctx->variant != kRenderStatic && getenv("TRT_DEBUG_TILES"))
   {
-    unsigned int q[3];
+    unsigned int q[2];
     TRT_HIP(ctx, hipStreamSynchronize(st));
     TRT_HIP(ctx, hipMemcpy(q, a.queue, sizeof q, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[trt] tiles: live=%u (heavy %u) clear=%u (cull=%u)\n", q[0] + q[2], q[0], q[1], a.tile_cull);
+    fprintf(stderr, "[trt] tiles: live=%u clear=%u (cull=%u)\n", q[0], q[1], a.tile_cull);
   }
   return TRT_OK;
 }

@@ -392,30 +392,21 @@ constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8
 // One lane per MACRO tile (32×8 pixels: one 128-B line of every first-hit stream per row).
 // A clear macro tile becomes ONE entry of the CLEAR list (written later with full-line
 // dwordx4 stores); any other macro tile contributes its 8×8 tiles to the LIVE list.
-// The LIVE list can be filled from both ends (a.tile_sort, off by default): tiles whose centre
-// ray hits a torus ("heavy") from the front, the others from the back, so that the waves —
-// which walk the list front to back — finish with cheap tiles.  Measured on MI355X this
-// longest-first order LOSES (render +10 %, classify 8 → 26 µs): kept only as an experiment.
-__device__ __forceinline__ uint32_t live_slot(const RenderArgs& a, uint32_t e, uint32_t n_heavy)
-{
-  return e < n_heavy ? e : a.tiles_cap - 1u - (e - n_heavy);
-}
-
+// (Ordering the LIVE list heavy-tiles-first was tried: render +10 %, classify 8 → 26 µs.)
 __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const SceneK scene, const RenderArgs a)
 {
   // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
   // per list per block of macro tiles (a returning atomic on a shared word costs ≈11 ns under
-  // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare).  Lists: 0 = LIVE heavy,
-  // 1 = CLEAR, 2 = LIVE light.
-  __shared__ uint32_t wave_cnt[3][kClassifyThreads / 64];
-  __shared__ uint32_t block_base[3];
+  // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare).  Lists: 0 = LIVE, 1 = CLEAR.
+  __shared__ uint32_t wave_cnt[2][kClassifyThreads / 64];
+  __shared__ uint32_t block_base[2];
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   // The list counters are double-buffered: this frame counts in a.queue, and zeroes the set
   // the NEXT frame will count in (no memset launch between frames; frames of one ctx are
   // ordered by the caller, include/trt.h).
-  if(t < 3)
+  if(t < 2)
     a.queue_next[t] = 0u;
   const bool     valid = t < macro_x * tiles_y;
   const uint32_t mx = t % macro_x, ty = t / macro_x;
@@ -425,36 +416,21 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   const uint32_t nlive = clear ? 0u : ntile;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  // heaviness of each live tile: does its centre ray hit anything?
-  uint32_t heavy_mask = 0;
-  if(a.tile_sort)
-    for(uint32_t j = 0; j < nlive; ++j)
-    {
-      const uint32_t x = min((tx0 + j) * 8 + 4, a.W - 1), ly = min(ty * 8 + 4, a.n_local_rows - 1);
-      v3 o, d;
-      raygen(a.g, a.toro, a.W, a.H, a.camera, x, image_row(a, ly), o, d);
-      float    th;
-      uint32_t dummy = 0;
-      if(closest_hit<float>(scene, o, d, kTMin, kTMax, th, dummy) >= 0)
-        heavy_mask |= 1u << j;
-    }
-  const uint32_t nheavy = (uint32_t)__popc(heavy_mask), nlight = nlive - nheavy;
-
-  // wave-level exclusive prefixes of the three counts
-  uint32_t pre[3] = {nheavy, clear ? 1u : 0u, nlight};
+  // wave-level exclusive prefixes of the two counts
+  uint32_t pre[2] = {nlive, clear ? 1u : 0u};
 #pragma unroll
   for(int off = 1; off < 64; off <<= 1)
 #pragma unroll
-    for(int k = 0; k < 3; ++k)
+    for(int k = 0; k < 2; ++k)
     {
       const uint32_t v = __shfl_up(pre[k], off, 64);
       if(lane >= (uint32_t)off) pre[k] += v;
     }
-  if(lane == 63)
-    for(int k = 0; k < 3; ++k) wave_cnt[k][wave] = pre[k];
-  pre[0] -= nheavy; pre[1] -= clear ? 1u : 0u; pre[2] -= nlight;
+  if(lane == 63) { wave_cnt[0][wave] = pre[0]; wave_cnt[1][wave] = pre[1]; }
+  pre[0] -= nlive;
+  pre[1] -= clear ? 1u : 0u;
   __syncthreads();
-  if(threadIdx.x < 3)
+  if(threadIdx.x < 2)
   {
     uint32_t sum = 0;
     for(uint32_t w = 0; w < kClassifyThreads / 64; ++w)
@@ -468,13 +444,9 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   __syncthreads();
   if(clear)
     a.tiles_clear[block_base[1] + wave_cnt[1][wave] + pre[1]] = tx0 | (ty << 16);
-  uint32_t ih = block_base[0] + wave_cnt[0][wave] + pre[0], il = block_base[2] + wave_cnt[2][wave] + pre[2];
+  const uint32_t il = block_base[0] + wave_cnt[0][wave] + pre[0];
   for(uint32_t j = 0; j < nlive; ++j)
-  {
-    const uint32_t packed = (tx0 + j) | (ty << 16);
-    if(heavy_mask & (1u << j)) a.tiles_live[ih++] = packed;
-    else a.tiles_live[a.tiles_cap - 1u - il++] = packed;
-  }
+    a.tiles_live[il + j] = (tx0 + j) | (ty << 16);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -571,8 +543,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   const int      n_tori  = S.n_tori;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
-  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)2));
+  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
   const uint32_t n_clear = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)1));
 
   // Queue state.  Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k caches the
@@ -582,7 +553,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   const uint32_t my_live_n  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;   // entries owned
   const uint32_t my_clear_n = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
   uint32_t k_live = 0, k_clear = 0;  // next owned entry (wave-uniform)
-  uint32_t live_cache  = lane < my_live_n ? ld1(a.tiles_live, (size_t)live_slot(a, g_wave + lane * n_waves, n_heavy)) : 0u;
+  uint32_t live_cache  = lane < my_live_n ? ld1(a.tiles_live, g_wave + (size_t)lane * n_waves) : 0u;
   uint32_t clear_cache = lane < my_clear_n ? ld1(a.tiles_clear, g_wave + (size_t)lane * n_waves) : 0u;
   settle_loads(live_cache, clear_cache);
   bool     exhausted = my_live_n == 0;
@@ -766,7 +737,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
           {
             if((k_live & 63u) == 0)
             {
-              live_cache = k_live + lane < my_live_n ? ld1(a.tiles_live, (size_t)live_slot(a, g_wave + (k_live + lane) * n_waves, n_heavy)) : 0u;
+              live_cache = k_live + lane < my_live_n ? ld1(a.tiles_live, g_wave + (size_t)(k_live + lane) * n_waves) : 0u;
               settle_loads(live_cache, clear_cache);
             }
             cur = __builtin_amdgcn_readlane(live_cache, k_live & 63u);
@@ -851,8 +822,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   const uint32_t lane    = threadIdx.x & 63;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_heavy = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
-  const uint32_t n_live  = n_heavy + __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)2));
+  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
   const uint32_t n_clear = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)1));
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
 
@@ -869,7 +839,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   {
     if((i & 63u) == 0)
     {
-      live_cache  = i + lane < my_live ? ld1(a.tiles_live, (size_t)live_slot(a, g_wave + (i + lane) * n_waves, n_heavy)) : 0u;
+      live_cache  = i + lane < my_live ? ld1(a.tiles_live, g_wave + (size_t)(i + lane) * n_waves) : 0u;
       clear_cache = i + lane < my_clear ? ld1(a.tiles_clear, g_wave + (size_t)(i + lane) * n_waves) : 0u;
       settle_loads(live_cache, clear_cache);
     }

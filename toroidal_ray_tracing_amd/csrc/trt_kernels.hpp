@@ -26,14 +26,12 @@ struct RenderArgs {
   trt_rendered_data* rendered;  // AoS, x*H+y                     (BEF rgen:72-73,111-112)
   unsigned long long* stats;    // [4]: primary, bounce, shadow tests, pixels (optional)
   // persistent kernel: tile lists built by tile_classify_kernel (packed tx | ty << 16)
-  unsigned int*       queue;        // [0] = #LIVE heavy, [1] = #CLEAR, [2] = #LIVE light tiles of this frame (zero on entry)
-  uint32_t            tiles_cap;    // capacity of tiles_live (= #tiles): heavy entries from the front, light from the back
+  unsigned int*       queue;        // [0] = #LIVE tiles, [1] = #CLEAR macro tiles of this frame (zero on entry)
   unsigned int*       queue_next;   // the counter set of the next frame, zeroed by this one
   uint32_t*           tiles_live;   // tiles that need ray tracing
   uint32_t*           tiles_clear;  // tiles whose every pixel misses every bounding sphere
   uint32_t            min_batch;    // persistent kernel: lanes needed to run a shader/refill round (default 24)
   uint32_t            tile_cull;    // 0: classify every tile as LIVE
-  uint32_t            tile_sort;    // 1: heavy tiles first (experiment, TRT_TILE_SORT)
   uint32_t            debug_skip;   // diagnostics (TRT_DEBUG_SKIP): 1 = skip clear tiles, 2 = skip traced tiles
   uint32_t            vec4_ok;      // W % 4 == 0 and all first-hit streams 16-B aligned: dwordx4 clears
 };
