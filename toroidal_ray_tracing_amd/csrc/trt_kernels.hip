@@ -831,6 +831,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
   // broadcast with v_readlane, so no load — and hence no s_waitcnt vmcnt that would drain the
   // output stores — sits between the tiles.  Clear macro tiles (pure stores) are interleaved
   // with the traced tiles: the HBM-bound half of the frame drains behind the VALU-bound half.
+  // Measured alternatives (4096², one process, interleaved rounds): dealing the CLEAR entries
+  // only over the waves that own a LIVE tile (no store-only tail of the grid) +21 %; tracing
+  // first and clearing afterwards +5 %, on odd waves only +4 %, on odd blocks only +2 %.
   const uint32_t my_live  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;
   const uint32_t my_clear = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
   const uint32_t n_iter = my_live > my_clear ? my_live : my_clear;
