@@ -55,8 +55,13 @@ enum {
   TRT_CAMERA_TOROIDAL = 1  /* BEF/shaders/raytrace.rgen:21-57                           */
 };
 
-/* ---- solver precision (BASELINE config 4: "FP64 root solve", FP32 I/O) ------------- */
-enum { TRT_SOLVE_F32 = 0, TRT_SOLVE_F64 = 1 };
+/* ---- root solver and its precision ---------------------------- */
+/* Default: the Fourier–Newton walk on the depressed quartic, FP32; _F64 = BASELINE config 4
+ * ("FP64 root solve", FP32 I/O).  _DK_* select the Durand–Kerner iteration north_star names
+ * (fixed sweep count, complex arithmetic): same interface and outputs, ≈10x the cost and a
+ * tolerance-based real-root test — kept as a measured alternative.  The
+ * persistent render variant implements the default solver only. */
+enum { TRT_SOLVE_F32 = 0, TRT_SOLVE_F64 = 1, TRT_SOLVE_DK_F32 = 2, TRT_SOLVE_DK_F64 = 3 };
 
 /* ---- uniform / push-constant blocks, byte-for-byte the reference's host structs ---- */
 
@@ -151,7 +156,7 @@ int         trt_version(void);                       /* MAJOR*1000 + MINOR      
 int         trt_create(int device, trt_ctx** out);   /* one ctx per device, not re-entrant */
 void        trt_destroy(trt_ctx* ctx);
 const char* trt_last_error(const trt_ctx* ctx);      /* ctx may be NULL: create errors   */
-int         trt_set_solver(trt_ctx* ctx, int precision); /* TRT_SOLVE_F32 | TRT_SOLVE_F64 */
+int         trt_set_solver(trt_ctx* ctx, int solver);    /* one of TRT_SOLVE_*                 */
 
 /* ---- trace(rays_in -> hits_out): closest hit of every ray against the scene -------- */
 /* Host buffers: copies in, launches, copies out, synchronises. */

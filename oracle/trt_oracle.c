@@ -39,7 +39,9 @@
 #define FMAX fmaxf
 #define FMIN fminf
 #define FABS fabsf
+#define TRT_DK_TOL 0.0009765625f /* 2^-10 */
 #include "trt_solve.inc"
+#undef TRT_DK_TOL
 #undef REAL
 #undef SUF
 #undef FMA
@@ -55,7 +57,9 @@
 #define FMAX fmax
 #define FMIN fmin
 #define FABS fabs
+#define TRT_DK_TOL 2.384185791015625e-07 /* 2^-22 */
 #include "trt_solve.inc"
+#undef TRT_DK_TOL
 #undef REAL
 #undef SUF
 #undef FMA
@@ -102,6 +106,7 @@ typedef struct {
   int          nmat;
   trt_material mat[TRT_MAX_MATERIALS];
   int          f64;
+  int          dk;   /* 1: Durand–Kerner root solve instead of the Fourier–Newton walk */
 } scene_t;
 
 static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
@@ -111,7 +116,8 @@ static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
     return TRT_E_SCENE;
   out->n    = (int)s->n_tori;
   out->nmat = (int)s->n_materials;
-  out->f64  = precision == TRT_SOLVE_F64;
+  out->f64  = precision == TRT_SOLVE_F64 || precision == TRT_SOLVE_DK_F64;
+  out->dk   = precision == TRT_SOLVE_DK_F32 || precision == TRT_SOLVE_DK_F64;
   for(int i = 0; i < out->n; ++i)
   {
     const trt_torus* t = &s->tori[i];
@@ -136,7 +142,7 @@ static inline int torus_hit(const scene_t* S, int i, v3 o, v3 d, float dd, float
     const double dd64   = fma(d64[2], d64[2], fma(d64[1], d64[1], d64[0] * d64[0]));
     double       t64;
     if(!torus_first_hit_f64(o64, d64, dd64, 1.0 / dd64, (double)tmin, (double)tmax, &S->k64[i],
-                            &t64, NULL))
+                            S->dk, &t64, NULL))
       return 0;
     const float tf = (float)t64;
     if(!(tf > tmin && tf < tmax)) /* rounding to FP32 may land on the open bounds */
@@ -145,7 +151,7 @@ static inline int torus_hit(const scene_t* S, int i, v3 o, v3 d, float dd, float
     return 1;
   }
   const float o32[3] = {o.x, o.y, o.z}, d32[3] = {d.x, d.y, d.z};
-  return torus_first_hit_f32(o32, d32, dd, inv_dd, tmin, tmax, &S->k32[i], t, NULL);
+  return torus_first_hit_f32(o32, d32, dd, inv_dd, tmin, tmax, &S->k32[i], S->dk, t, NULL);
 }
 
 /* Closest hit over all tori (role of traceRayEXT + BVH, REFL/shaders/raytrace.rgen:64-75):
@@ -560,14 +566,15 @@ int oracle_torus_first_hit(const trt_torus* T, const float* o, const float* d, f
                            float tmax, int precision, double* t_out, int* evals)
 {
   int ne = 0, hit;
-  if(precision == TRT_SOLVE_F64)
+  const int dk = precision == TRT_SOLVE_DK_F32 || precision == TRT_SOLVE_DK_F64;
+  if(precision == TRT_SOLVE_F64 || precision == TRT_SOLVE_DK_F64)
   {
     torus_k_f64 k;
     torus_prepare_f64(T, &k);
     const double o64[3] = {o[0], o[1], o[2]}, d64[3] = {d[0], d[1], d[2]};
     const double dd = fma(d64[2], d64[2], fma(d64[1], d64[1], d64[0] * d64[0]));
     double t;
-    hit = torus_first_hit_f64(o64, d64, dd, 1.0 / dd, tmin, tmax, &k, &t, &ne);
+    hit = torus_first_hit_f64(o64, d64, dd, 1.0 / dd, tmin, tmax, &k, dk, &t, &ne);
     if(hit) *t_out = t;
   }
   else
@@ -576,7 +583,7 @@ int oracle_torus_first_hit(const trt_torus* T, const float* o, const float* d, f
     torus_prepare_f32(T, &k);
     const float dd = fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0]));
     float t;
-    hit = torus_first_hit_f32(o, d, dd, 1.0f / dd, tmin, tmax, &k, &t, &ne);
+    hit = torus_first_hit_f32(o, d, dd, 1.0f / dd, tmin, tmax, &k, dk, &t, &ne);
     if(hit) *t_out = (double)t;
   }
   if(evals) *evals = ne;

@@ -43,7 +43,8 @@ SCENES = {
 
 
 @pytest.mark.parametrize("scene", list(SCENES))
-@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64, abi.TRT_SOLVE_DK_F32, abi.TRT_SOLVE_DK_F64],
+                         ids=["f32", "f64", "dk32", "dk64"])
 def test_trace_bit_exact_vs_oracle(tr, oracle, scene, precision):
     sc = SCENES[scene]()
     o, d = seeded_rays(100_003, 1234, center=sc.tori_list()[0][0], box=5.0, reach=2.4)
@@ -177,6 +178,39 @@ def test_render_fp64_nested(tr, oracle, variant):
     tr.set_render_variant(variant)
     try:
         check_render(tr, oracle, sc, g, pc, W, H, 0, abi.TRT_SOLVE_F64)
+    finally:
+        tr.set_solver(abi.TRT_SOLVE_F32)
+        tr.set_render_variant("listed")
+
+
+@pytest.mark.parametrize("variant", ["static", "listed"])
+@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_DK_F32, abi.TRT_SOLVE_DK_F64], ids=["dk32", "dk64"])
+@pytest.mark.parametrize("name", ["mirror_d5", "nested_d5", "toroidal_interior"])
+def test_render_durand_kerner(tr, oracle, name, precision, variant):
+    """The Durand–Kerner solver (north_star's T2) behind the same render path: bit-exact first-hit
+    record and query counts against the oracle's restatement of the same iteration."""
+    W, H = 136, 104
+    sc, g, pc, cam = RENDERS[name](W, H)
+    tr.set_solver(precision)
+    tr.set_render_variant(variant)
+    tr.enable_stats(True)
+    try:
+        _, _, wstats = check_render(tr, oracle, sc, g, pc, W, H, cam, precision)
+        assert tr.stats() == {**wstats}
+    finally:
+        tr.enable_stats(False)
+        tr.set_solver(abi.TRT_SOLVE_F32)
+        tr.set_render_variant("listed")
+
+
+def test_durand_kerner_not_in_persistent_variant(tr):
+    from toroidal_ray_tracing_amd.tracer import TrtError
+    tr.set_solver(abi.TRT_SOLVE_DK_F32)
+    tr.set_render_variant("persistent")
+    try:
+        with pytest.raises(TrtError) as e:
+            tr.render(camera.single_torus_scene(), camera.baseline_camera(16, 16), camera.baseline_push(2), 16, 16)
+        assert e.value.code == abi.TRT_E_INVALID
     finally:
         tr.set_solver(abi.TRT_SOLVE_F32)
         tr.set_render_variant("listed")

@@ -27,11 +27,11 @@ def timeit(fn, rounds=7, frames=10):
     return statistics.median(out)
 
 
-def render_case(name, sc, g, pc, W, H, cam=0, f64=False, variants=("listed", "persistent", "static")):
+def render_case(name, sc, g, pc, W, H, cam=0, f64=False, variants=("listed", "persistent", "static"), solver=None):
     rgba = torch.empty(H, W, 4, device=dev)
     hits = {k: torch.empty(H * W, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
     hp = {k: v.data_ptr() for k, v in hits.items()}
-    tr.set_solver(abi.TRT_SOLVE_F64 if f64 else abi.TRT_SOLVE_F32)
+    tr.set_solver(solver if solver is not None else abi.TRT_SOLVE_F64 if f64 else abi.TRT_SOLVE_F32)
     for v in variants:
         tr.set_render_variant(v)
         tr.enable_stats(True)
@@ -85,6 +85,10 @@ trace_case("C2 2048^2 primary, 0 bounces", camera.single_torus_scene(), camera.b
 render_case("C2 as render, 2048^2 maxDepth 1", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(1), W, W)
 W = 4096
 render_case("C3 4096^2 maxDepth 5", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W)
+render_case("C3 with Durand-Kerner FP32", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W,
+            variants=("listed",), solver=abi.TRT_SOLVE_DK_F32)
+render_case("C3 with Durand-Kerner FP64", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W,
+            variants=("listed",), solver=abi.TRT_SOLVE_DK_F64)
 render_case("C4 8 nested tori, FP64 solve", camera.nested_tori_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W, f64=True)
 render_case("C4' 8 nested tori, FP32 solve", camera.nested_tori_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W)
 pc = camera.baseline_push(5); pc.rho = 4.0

@@ -88,7 +88,7 @@ struct SceneK {
   int            n_tori;
   int            n_mat;
   int            f64;   // 1: FP64 root solve (BASELINE config 4), FP32 I/O
-  int            pad_;
+  int            dk;    // 1: Durand–Kerner root solve (TRT_SOLVE_DK_*), 0: Fourier–Newton walk
   TorusK<float>  k32[TRT_MAX_TORI];
   TorusK<double> k64[TRT_MAX_TORI];
   TorusShade     shade[TRT_MAX_TORI];
@@ -309,6 +309,79 @@ struct TorusTest {
   // true when step_iter() applies to this lane
   __device__ __forceinline__ bool iterating() const { return mode == M_FWD || mode == M_BWD; }
 
+  // T2, alternative solver (TRT_SOLVE_DK_*): Durand–Kerner iteration on the monic depressed
+  // quartic u⁴ + p·u² + q·u + s — four complex iterates from the spiral (0.4+0.9i)^k scaled by the
+  // bounding-sphere radius, updated in place for a FIXED number of sweeps (every lane runs the
+  // same trip count), only + - * / fma.  Real candidates (|Im| <= tol·scale) get two guarded
+  // Newton steps; the smallest one inside [lo,hi] becomes `root`.  (tests/ compare it bit for bit
+  // with a CPU restatement.)  Call after a successful setup(); then finish().
+  __device__ __forceinline__ void solve_dk(Real inv_dd, Real Rb2)
+  {
+    constexpr int  kSweeps = 24;
+    constexpr Real kTol = sizeof(Real) == 4 ? Real(0.0009765625) : Real(2.384185791015625e-07);  // 2^-10 / 2^-22
+    const Real CR[4] = {Real(1.0), Real(0.4), Real(-0.65), Real(-0.908)};
+    const Real CI[4] = {Real(0.0), Real(0.9), Real(0.72), Real(-0.297)};
+    const Real iA4 = inv_dd * inv_dd;
+    const Real p = P2 * iA4, q = Q1 * iA4, s = S0 * iA4;
+    const Real sc  = sqrt_(Rb2 * inv_dd);
+    const Real tol = kTol * sc;
+    const Real lo  = A;   // setup() leaves the window start in A (= B = xe)
+    Real zr[4], zi[4];
+#pragma unroll
+    for(int k = 0; k < 4; ++k) { zr[k] = sc * CR[k]; zi[k] = sc * CI[k]; }
+#pragma unroll 1
+    for(int sweep = 0; sweep < kSweeps; ++sweep)
+    {
+#pragma unroll
+      for(int k = 0; k < 4; ++k)
+      {
+        const Real x = zr[k], y = zi[k];
+        const Real ar = fma_(x, x, -(y * y)) + p, ai = (x + x) * y;
+        const Real br = fma_(ar, x, -(ai * y)) + q, bi = fma_(ar, y, ai * x);
+        const Real fr = fma_(br, x, -(bi * y)) + s, fi = fma_(br, y, bi * x);
+        Real dr = Real(1), di = Real(0);
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+          if(j != k)
+          {
+            const Real er = x - zr[j], ei = y - zi[j];
+            const Real nr = fma_(dr, er, -(di * ei)), ni = fma_(dr, ei, di * er);
+            dr = nr; di = ni;
+          }
+        const Real den = fma_(dr, dr, di * di);
+        if(den > Real(0) && den < Real(__builtin_inf()))
+        {
+          const Real inv = Real(1) / den;
+          zr[k] = x - fma_(fr, dr, fi * di) * inv;
+          zi[k] = y - fma_(fi, dr, -(fr * di)) * inv;
+        }
+      }
+    }
+    bool f = false;
+    Real best = Real(0);
+    const Real A4x4 = Real(4) * A4, P2x2 = Real(2) * P2;
+#pragma unroll
+    for(int k = 0; k < 4; ++k)
+    {
+      if(!(abs_(zi[k]) <= tol))
+        continue;
+      Real u = zr[k];
+#pragma unroll
+      for(int n = 0; n < 2; ++n)
+      {
+        const Real e1 = fma_(A4 * u, u, P2), e2 = fma_(e1, u, Q1), fu = fma_(e2, u, S0);
+        const Real g1 = fma_(A4x4 * u, u, P2x2), du = fma_(g1, u, Q1);
+        const Real st = fu / du;
+        if(abs_(st) <= tol)
+          u = u - st;
+      }
+      if(u >= lo && u <= hi && (!f || u < best)) { best = u; f = true; }
+    }
+    found = f;
+    root  = best;
+    mode  = M_DONE;
+  }
+
   // T2b: one Newton step on g(u) = (ρ-R)² + py² - r², whose rounding error scales with r²
   // instead of R⁴ (a step above r/32 — grazing, g' ≈ 0 — is discarded); then t = u + tc and
   // the open-interval test of the closest-hit query.
@@ -335,7 +408,7 @@ struct TorusTest {
   }
 };
 
-template <class Real>
+template <class Real, bool DK = false>
 __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
                                                 Real dz_, Real dd, Real inv_dd, Real tmin, Real tmax,
                                                 const TorusK<Real>& T, Real& t_out)
@@ -343,14 +416,19 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
   TorusTest<Real> q;
   if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))
     return false;
-  // per trip: the cheap iteration-only step when every running lane of the wave is iterating
-  bool run = true;
-  while(run)
+  if(DK)
+    q.solve_dk(inv_dd, T.Rb2);
+  else
   {
-    if(__any(!q.iterating()))
-      run = q.step();
-    else
-      run = q.step_iter();
+    // per trip: the cheap iteration-only step when every running lane of the wave is iterating
+    bool run = true;
+    while(run)
+    {
+      if(__any(!q.iterating()))
+        run = q.step();
+      else
+        run = q.step_iter();
+    }
   }
   return q.finish(dx_, dy_, dz_, tmin, tmax, T, t_out);
 }
@@ -385,11 +463,11 @@ __device__ __forceinline__ bool round_t(double t, float tmin, float tmax, float&
 }
 
 // One ray against torus i; t rounded to FP32.
-template <class Real>
+template <class Real, bool DK = false>
 __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t)
 {
   Real tt;
-  if(!torus_first_hit<Real>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.dd, r.inv_dd, r.tmin, r.tmax,
+  if(!torus_first_hit<Real, DK>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.dd, r.inv_dd, r.tmin, r.tmax,
                             torus_k<Real>(S, i), tt))
     return false;
   return round_t(tt, tmin, tmax, t);
@@ -397,7 +475,7 @@ __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Rea
 
 // Closest hit over the tori — the role of traceRayEXT + BVH (REFL/shaders/raytrace.rgen:64-75).
 // Returns the torus index or -1; `tests` counts ray–torus tests.
-template <class Real>
+template <class Real, bool DK = false>
 __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
                                            float& t_out, uint32_t& tests)
 {
@@ -409,7 +487,7 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
   {
     float t;
     ++tests;
-    if(torus_hit<Real>(S, i, r, tmin, tmax, t) && t < best)
+    if(torus_hit<Real, DK>(S, i, r, tmin, tmax, t) && t < best)
     {
       best = t;
       id   = i;
@@ -420,7 +498,7 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
 }
 
 // Any hit — the shadow query with gl_RayFlagsTerminateOnFirstHitEXT (REFL rchit:206-219).
-template <class Real>
+template <class Real, bool DK = false>
 __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
                                         uint32_t& tests)
 {
@@ -430,7 +508,7 @@ __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin,
   {
     float t;
     ++tests;
-    if(torus_hit<Real>(S, i, r, tmin, tmax, t))
+    if(torus_hit<Real, DK>(S, i, r, tmin, tmax, t))
       return true;
   }
   return false;

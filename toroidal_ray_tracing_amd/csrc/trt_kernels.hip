@@ -168,7 +168,7 @@ constexpr float kTMax = 10000.0f;  // rgen:52
 // ------------------------------------------------------------------------------------------
 // trace(rays_in → hits_out)
 // ------------------------------------------------------------------------------------------
-template <class Real>
+template <class Real, bool DK>
 __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const TraceArgs a)
 {
   __shared__ SceneK S;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
     const v3 o = {a.rays.ox[i], a.rays.oy[i], a.rays.oz[i]};
     const v3 d = {a.rays.dx[i], a.rays.dy[i], a.rays.dz[i]};
     float     t;
-    const int id = closest_hit<Real>(S, o, d, a.tmin, a.tmax, t, tests);
+    const int id = closest_hit<Real, DK>(S, o, d, a.tmin, a.tmax, t, tests);
     v3 P = {0.0f, 0.0f, 0.0f}, N = {0.0f, 0.0f, 0.0f};
     if(id >= 0)
     {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
 // ------------------------------------------------------------------------------------------
 // One pixel, start to finish, on one lane: the reference's raygen main() with the closest-hit,
 // miss and shadow-miss shaders inlined (REFL/shaders/raytrace.rgen:40-88).
-template <class Real>
+template <class Real, bool DK>
 __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a, uint32_t x, uint32_t y, uint32_t ly,
                                             uint32_t& n_primary, uint32_t& n_bounce, uint32_t& n_shadow)
 {
@@ -227,7 +227,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
   {
     v3    prdHit, nextO = origin, nextD = direction;
     float t;
-    const int id = closest_hit<Real>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce);
+    const int id = closest_hit<Real, DK>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce);
     if(id < 0)
     {
       prdHit = {a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f};  // rmiss:37
@@ -248,7 +248,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
       }
       bool shadowed = false;
       if(h.wantShadow)
-        shadowed = any_hit<Real>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow);  // rchit:114-131
+        shadowed = any_hit<Real, DK>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow);  // rchit:114-131
       prdHit = hit_end(S, h, direction, shadowed, attenuation, done, nextO, nextD);
     }
     hitValue.x = fma_(prdHit.x, attenuation.x, hitValue.x);                // rgen:76
@@ -266,7 +266,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
   if(rd) st4(rd + 4, c);                                                   // BEF rgen:111
 }
 
-template <class Real, int TW>
+template <class Real, int TW, bool DK>
 __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, const RenderArgs a)
 {
   __shared__ SceneK S;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
   const uint32_t ly = (tile / tiles_x) * TH + (lane / TW);
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
   if(x < a.W && ly < a.n_local_rows)
-    trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+    trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
   if(a.stats)
   {
     wave_add(&a.stats[0], n_primary);
@@ -811,8 +811,8 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 #ifndef TRT_LISTED_WAVES
 #define TRT_LISTED_WAVES 5
 #endif
-template <class Real, bool STATS>
-__global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
+template <class Real, bool STATS, bool DK>
+__global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
 {
   __shared__ SceneK     S;
   __shared__ RenderArgs A_lds;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) vo
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
       const uint32_t x = (packed & 0xffffu) * 8 + (ln & 7), ly = (packed >> 16) * 8 + (ln >> 3);
       if(x < a.W && ly < a.n_local_rows)
-        trace_pixel<Real>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+        trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
     }
   }
   if(a.debug_skip & 4u)   // experiment: all clear tiles after the traced ones
@@ -1008,10 +1008,10 @@ hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t str
     return hipSuccess;
   const uint64_t want = (a.rays.n + 255) / 256;
   const uint32_t grid = (uint32_t)(want < 256u * 16u ? want : 256u * 16u);
-  if(scene.f64)
-    hipLaunchKernelGGL(trace_kernel<double>, dim3(grid), dim3(256), 0, stream, scene, a);
-  else
-    hipLaunchKernelGGL(trace_kernel<float>, dim3(grid), dim3(256), 0, stream, scene, a);
+  if(scene.f64 && scene.dk) hipLaunchKernelGGL((trace_kernel<double, true>), dim3(grid), dim3(256), 0, stream, scene, a);
+  else if(scene.f64) hipLaunchKernelGGL((trace_kernel<double, false>), dim3(grid), dim3(256), 0, stream, scene, a);
+  else if(scene.dk) hipLaunchKernelGGL((trace_kernel<float, true>), dim3(grid), dim3(256), 0, stream, scene, a);
+  else hipLaunchKernelGGL((trace_kernel<float, false>), dim3(grid), dim3(256), 0, stream, scene, a);
   return hipGetLastError();
 }
 
@@ -1042,18 +1042,20 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       if(const char* e = getenv("TRT_LISTED_THREADS")) bthreads = (uint32_t)atoi(e);
       const uint32_t wpb = bthreads / 64;
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
-      if(scene.f64)
-      {
-        if(a.stats) hipLaunchKernelGGL((render_listed_kernel<double, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
-        else hipLaunchKernelGGL((render_listed_kernel<double, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
-      }
-      else
-      {
-        if(a.stats) hipLaunchKernelGGL((render_listed_kernel<float, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
-        else hipLaunchKernelGGL((render_listed_kernel<float, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);
-      }
+#define TRT_LAUNCH_LISTED(REAL, DK_)                                                                                   \
+  do {                                                                                                                 \
+    if(a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, DK_>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);  \
+    else hipLaunchKernelGGL((render_listed_kernel<REAL, false, DK_>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);        \
+  } while(0)
+      if(scene.f64 && scene.dk) TRT_LAUNCH_LISTED(double, true);
+      else if(scene.f64) TRT_LAUNCH_LISTED(double, false);
+      else if(scene.dk) TRT_LAUNCH_LISTED(float, true);
+      else TRT_LAUNCH_LISTED(float, false);
+#undef TRT_LAUNCH_LISTED
       return hipGetLastError();
     }
+    if(scene.dk)
+      return hipErrorInvalidValue;  // the persistent variant implements the default solver only (trt_api.hip checks)
     const uint32_t grid = (uint32_t)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);
     if(scene.f64)
       hipLaunchKernelGGL(render_persistent_kernel<double>, dim3(grid), dim3(256), 0, stream, scene, a);
@@ -1067,14 +1069,15 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
   if(tw != 8 && tw != 16 && tw != 32 && tw != 64) tw = 8;
   const uint64_t stiles = (uint64_t)((a.W + tw - 1) / tw) * ((a.n_local_rows + 64 / tw - 1) / (64 / tw));
   const uint32_t grid = (uint32_t)((stiles + 3) / 4);
-#define TRT_LAUNCH_STATIC(REAL, TW_) \
-  hipLaunchKernelGGL((render_static_kernel<REAL, TW_>), dim3(grid), dim3(256), 0, stream, scene, a)
-  if(scene.f64)
-    TRT_LAUNCH_STATIC(double, 8);
-  else if(tw == 16) TRT_LAUNCH_STATIC(float, 16);
-  else if(tw == 32) TRT_LAUNCH_STATIC(float, 32);
-  else if(tw == 64) TRT_LAUNCH_STATIC(float, 64);
-  else TRT_LAUNCH_STATIC(float, 8);
+#define TRT_LAUNCH_STATIC(REAL, TW_, DK_) \
+  hipLaunchKernelGGL((render_static_kernel<REAL, TW_, DK_>), dim3(grid), dim3(256), 0, stream, scene, a)
+  if(scene.f64 && scene.dk) TRT_LAUNCH_STATIC(double, 8, true);
+  else if(scene.f64) TRT_LAUNCH_STATIC(double, 8, false);
+  else if(scene.dk) TRT_LAUNCH_STATIC(float, 8, true);
+  else if(tw == 16) TRT_LAUNCH_STATIC(float, 16, false);
+  else if(tw == 32) TRT_LAUNCH_STATIC(float, 32, false);
+  else if(tw == 64) TRT_LAUNCH_STATIC(float, 64, false);
+  else TRT_LAUNCH_STATIC(float, 8, false);
 #undef TRT_LAUNCH_STATIC
   return hipGetLastError();
 }
