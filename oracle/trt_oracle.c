@@ -107,6 +107,7 @@ typedef struct {
   trt_material mat[TRT_MAX_MATERIALS];
   int          f64;
   int          dk;   /* 1: Durand–Kerner root solve instead of the Fourier–Newton walk */
+  int          order[TRT_MAX_TORI]; /* test order: descending bounding radius R + r, ties by index */
 } scene_t;
 
 static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
@@ -128,6 +129,20 @@ static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
     torus_prepare_f64(t, &out->k64[i]);
   }
   memcpy(out->mat, s->materials, sizeof(trt_material) * (size_t)out->nmat);
+  /* Test order (build-defined, like the torus arithmetic): largest bounding sphere first, so
+   * that an enclosing shell is hit before the shells inside it and the later tests are cut off
+   * by the shrinking interval (closest_hit).  Stable insertion sort on the FP32 sum R + r. */
+  for(int i = 0; i < out->n; ++i)
+  {
+    const float key = s->tori[i].R + s->tori[i].r;
+    int k = i;
+    while(k > 0 && s->tori[out->order[k - 1]].R + s->tori[out->order[k - 1]].r < key)
+    {
+      out->order[k] = out->order[k - 1];
+      --k;
+    }
+    out->order[k] = i;
+  }
   return TRT_OK;
 }
 
@@ -162,10 +177,14 @@ static int closest_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, flo
   const float dd = dot3(d, d), inv_dd = 1.0f / dd;
   int   id   = -1;
   float best = INFINITY;
-  for(int i = 0; i < S->n; ++i)
+  for(int k = 0; k < S->n; ++k)
   {
+    /* the interval of every later test ends at the closest hit so far (open interval: a hit
+     * returned by torus_hit is already closer; equal t keeps the torus tested first) */
+    const int   i  = S->order[k];
+    const float tm = fminf(tmax, best);
     float t;
-    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, &t, tests) && t < best)
+    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tm, &t, tests))
     {
       best = t;
       id   = i;
@@ -175,14 +194,14 @@ static int closest_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, flo
   return id;
 }
 
-/* Any hit (gl_RayFlagsTerminateOnFirstHitEXT shadow query, REFL/shaders/raytrace.rchit:206-219). */
+/* Any hit (shadow query: gl_RayFlagsTerminateOnFirstHitEXT, REFL/shaders/raytrace.rchit:114-131). */
 static int any_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, uint64_t* tests)
 {
   const float dd = dot3(d, d), inv_dd = 1.0f / dd;
-  for(int i = 0; i < S->n; ++i)
+  for(int k = 0; k < S->n; ++k)
   {
     float t;
-    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tmax, &t, tests))
+    if(torus_hit(S, S->order[k], o, d, dd, inv_dd, tmin, tmax, &t, tests))
       return 1;
   }
   return 0;

@@ -133,6 +133,18 @@ int build_scene(trt_ctx* ctx, const trt_scene* s, SceneK& out)
     torus_prepare<double>(t, out.k64[i]);
     out.shade[i] = {t.center[0], t.center[1], t.center[2], t.R, t.matId};
   }
+  // test order: largest bounding sphere first (stable insertion sort on the FP32 sum R + r)
+  for(uint32_t i = 0; i < s->n_tori; ++i)
+  {
+    const float key = s->tori[i].R + s->tori[i].r;
+    uint32_t k = i;
+    while(k > 0 && s->tori[out.order[k - 1]].R + s->tori[out.order[k - 1]].r < key)
+    {
+      out.order[k] = out.order[k - 1];
+      --k;
+    }
+    out.order[k] = (int)i;
+  }
   for(uint32_t i = 0; i < s->n_materials; ++i)
   {
     const trt_material& m = s->materials[i];

@@ -89,6 +89,7 @@ struct SceneK {
   int            n_mat;
   int            f64;   // 1: FP64 root solve (BASELINE config 4), FP32 I/O
   int            dk;    // 1: Durand–Kerner root solve (TRT_SOLVE_DK_*), 0: Fourier–Newton walk
+  int            order[TRT_MAX_TORI];  // test order: descending bounding radius R + r, ties by index
   TorusK<float>  k32[TRT_MAX_TORI];
   TorusK<double> k64[TRT_MAX_TORI];
   TorusShade     shade[TRT_MAX_TORI];
@@ -96,21 +97,21 @@ struct SceneK {
 };
 
 // Copy the scene constants from the kernel-argument segment into LDS — only the records in use
-// (n_tori solver records of the active precision, n_tori shading records, n_mat materials):
-// 30 dwords for one FP32 torus instead of the 372 of the full struct, one load per thread.
+// (header + test order, n_tori solver records of the active precision, n_tori shading records,
+// n_mat materials): 38 dwords for one FP32 torus instead of the 380 of the full struct, one load per thread.
 // Reads in the hot loops then hit LDS at wave-uniform (broadcast) or material-indexed addresses.
 __device__ __forceinline__ void stage_scene(SceneK* lds, const SceneK& arg)
 {
-  static_assert(sizeof(SceneK) == 4 * (4 + 80 + 160 + 40 + 88) && sizeof(TorusK<float>) == 40 && sizeof(TorusShade) == 20
+  static_assert(sizeof(SceneK) == 4 * (12 + 80 + 160 + 40 + 88) && sizeof(TorusK<float>) == 40 && sizeof(TorusShade) == 20
                     && sizeof(MaterialK) == 44, "SceneK layout");
   const uint32_t* src = reinterpret_cast<const uint32_t*>(&arg);
   uint32_t*       dst = reinterpret_cast<uint32_t*>(lds);
   const uint32_t  n = (uint32_t)arg.n_tori, nm = (uint32_t)arg.n_mat;
-  const uint32_t  c0 = 4, c1 = c0 + (arg.f64 ? 0u : 10u * n), c2 = c1 + (arg.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
+  const uint32_t  c0 = 12, c1 = c0 + (arg.f64 ? 0u : 10u * n), c2 = c1 + (arg.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
                  c4 = c3 + 11u * nm;
   for(uint32_t i = threadIdx.x; i < c4; i += blockDim.x)
   {
-    const uint32_t off = i < c0 ? i : i < c1 ? 4u + (i - c0) : i < c2 ? 84u + (i - c1) : i < c3 ? 244u + (i - c2) : 284u + (i - c3);
+    const uint32_t off = i < c0 ? i : i < c1 ? 12u + (i - c0) : i < c2 ? 92u + (i - c1) : i < c3 ? 252u + (i - c2) : 292u + (i - c3);
     dst[off] = src[off];
   }
   __syncthreads();
@@ -462,18 +463,21 @@ __device__ __forceinline__ bool round_t(double t, float tmin, float tmax, float&
   return true;
 }
 
-// One ray against torus i; t rounded to FP32.
+// One ray against torus i over the open interval (tmin, tmax); t rounded to FP32.
 template <class Real, bool DK = false>
 __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t)
 {
   Real tt;
-  if(!torus_first_hit<Real, DK>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.dd, r.inv_dd, r.tmin, r.tmax,
-                            torus_k<Real>(S, i), tt))
+  if(!torus_first_hit<Real, DK>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.dd, r.inv_dd, r.tmin, (Real)tmax,
+                                torus_k<Real>(S, i), tt))
     return false;
   return round_t(tt, tmin, tmax, t);
 }
 
 // Closest hit over the tori — the role of traceRayEXT + BVH (REFL/shaders/raytrace.rgen:64-75).
+// Tori are tested in S.order (largest bounding sphere first) and the interval of every later
+// test ends at the closest hit so far: behind an enclosing shell the remaining tests end in
+// their window clip without a Newton step.  Equal t keeps the torus tested first.
 // Returns the torus index or -1; `tests` counts ray–torus tests.
 template <class Real, bool DK = false>
 __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
@@ -483,11 +487,12 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
   r.set(o, d, tmin, tmax);
   int   id   = -1;
   float best = __builtin_inff();
-  for(int i = 0; i < S.n_tori; ++i)
+  for(int k = 0; k < S.n_tori; ++k)
   {
+    const int i = S.order[k];
     float t;
     ++tests;
-    if(torus_hit<Real, DK>(S, i, r, tmin, tmax, t) && t < best)
+    if(torus_hit<Real, DK>(S, i, r, tmin, min_(tmax, best), t))
     {
       best = t;
       id   = i;
@@ -504,11 +509,11 @@ __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin,
 {
   RayK<Real> r;
   r.set(o, d, tmin, tmax);
-  for(int i = 0; i < S.n_tori; ++i)
+  for(int k = 0; k < S.n_tori; ++k)
   {
     float t;
     ++tests;
-    if(torus_hit<Real, DK>(S, i, r, tmin, tmax, t))
+    if(torus_hit<Real, DK>(S, S.order[k], r, tmin, tmax, t))
       return true;
   }
   return false;

@@ -751,8 +751,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         if(kind == K_SHADOW) ++n_shadow;
         else if(depth == 0) ++n_primary;
         else ++n_bounce;
-        if(tst.setup(rk.ox, rk.oy, rk.oz, rk.dx, rk.dy, rk.dz, rk.dd, rk.inv_dd, rk.tmin, rk.tmax,
-                     torus_k<Real>(S, ti)))
+        // closest-hit queries end the interval of every later test at the closest hit so far
+        if(tst.setup(rk.ox, rk.oy, rk.oz, rk.dx, rk.dy, rk.dz, rk.dd, rk.inv_dd, rk.tmin,
+                     (Real)(kind == K_CLOSEST ? min_(q_tmax, best_t) : q_tmax), torus_k<Real>(S, S.order[ti])))
           inflight = true;
         else
           ++ti;  // culled by the bounding sphere / window: this test is a miss
@@ -782,11 +783,12 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
       unconsumed = false;
       Real  tt;
       float t;
-      if(tst.finish(rk.dx, rk.dy, rk.dz, rk.tmin, rk.tmax, torus_k<Real>(S, ti), tt)
-         && round_t(tt, kTMin, q_tmax, t))
+      const float tm = kind == K_CLOSEST ? min_(q_tmax, best_t) : q_tmax;   // the interval setup() used
+      if(tst.finish(rk.dx, rk.dy, rk.dz, rk.tmin, (Real)tm, torus_k<Real>(S, S.order[ti]), tt)
+         && round_t(tt, kTMin, tm, t))
       {
         if(kind == K_SHADOW) shadow_hit = true;
-        else if(t < best_t) { best_t = t; best_id = ti; }
+        else { best_t = t; best_id = S.order[ti]; }
       }
       ++ti;
     }
