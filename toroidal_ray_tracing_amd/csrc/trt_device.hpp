@@ -265,7 +265,10 @@ struct TorusTest {
     const bool go     = (isF && !cap && !f_no && !f_cv) || (isB && !cap && !b_stop && !b_left && xn != u);
 
     const bool hit_x = e_hit || f_flip || cap || f_cv || b_hitx;
-    const bool done  = (leave && !more) || hit_x || b_hitA;
+    // a forward run that proves "no root" in the LAST piece decides the test: nothing is
+    // evaluated at hi any more (that evaluation carried no information)
+    const bool last_no = f_no && !(B2 < hi);
+    const bool done  = (leave && !more) || hit_x || b_hitA || last_no;
     found = hit_x || b_hitA;
     root  = b_hitA ? A2 : u;
     A = A2; B = B2; sigma = sigma2; sref = sref2; it = it2;
@@ -298,8 +301,9 @@ struct TorusTest {
     const bool b_hitA = !fwd && !cap && !b_stop && !(xn > A);
     const bool hit_x  = fwd ? (flip || cap || (!f_no && xn == u))
                             : (cap || b_stop || (!b_hitA && xn == u));
-    const bool done   = hit_x || b_hitA;
-    found = done;
+    const bool last_no = f_no && !(B < hi);   // "no root" in the last piece: the test is a miss
+    const bool done   = hit_x || b_hitA || last_no;
+    found = hit_x || b_hitA;
     root  = b_hitA ? A : u;
     it    = it2;
     xe    = f_no ? B : (done ? u : xn);
