@@ -391,24 +391,44 @@ CAMERAS = [
 ]
 
 
-@pytest.mark.parametrize("variant", ["persistent", "listed"])
+@pytest.mark.parametrize("variant,fine", [("persistent", 0), ("persistent", 1), ("listed", 0), ("listed", 1)])
 @pytest.mark.parametrize("cam", range(len(CAMERAS)))
 @pytest.mark.parametrize("scene", ["single", "nested8", "thin_offset"])
-def test_tile_classification_is_conservative(tr, oracle, cam, variant, scene):
-    """Frames from cameras around, inside and behind the tori: the CLEAR/LIVE classification may
-    never change a pixel — first-hit records bit-exact, query counts identical."""
+def test_tile_classification_is_conservative(tr, oracle, cam, variant, fine, scene):
+    """Frames from cameras around, inside and behind the tori: the CLEAR/LIVE classification —
+    the macro-tile level and the finer per-tile level with the distance-function march (default
+    for the toroidal camera only, forced here) — may never change a pixel: first-hit records
+    bit-exact, query counts identical."""
     eye, center, fov, W, H = CAMERAS[cam]
     sc = SCENES[scene]()
     g = camera.globals_for(eye, center, W, H, fov_deg=fov)
     pc = camera.baseline_push(4)
     tr.set_render_variant(variant)
     tr.enable_stats(True)
+    os.environ["TRT_FINE_CLASSIFY"] = str(fine)
     try:
         _, _, wstats = check_render(tr, oracle, sc, g, pc, W, H, 0)
         assert tr.stats() == wstats
     finally:
+        os.environ.pop("TRT_FINE_CLASSIFY", None)
         tr.enable_stats(False)
         tr.set_render_variant("listed")
+
+
+@pytest.mark.parametrize("fine", [0, 1])
+@pytest.mark.parametrize("name", ["toroidal_interior", "toroidal_survey", "toroidal_tilted"])
+def test_toroidal_classification_levels(tr, oracle, name, fine):
+    """Both classification levels under the toroidal camera (varying ray origins)."""
+    W, H = 200, 136
+    sc, g, pc, cam = RENDERS[name](W, H)
+    os.environ["TRT_FINE_CLASSIFY"] = str(fine)
+    tr.enable_stats(True)
+    try:
+        _, _, wstats = check_render(tr, oracle, sc, g, pc, W, H, cam)
+        assert tr.stats() == wstats
+    finally:
+        os.environ.pop("TRT_FINE_CLASSIFY", None)
+        tr.enable_stats(False)
 
 
 def test_post_pass_bit_exact(tr, oracle):

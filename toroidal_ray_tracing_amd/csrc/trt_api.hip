@@ -480,8 +480,8 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
                                     "use the listed or static variant with TRT_SOLVE_DK_*");
   if(ctx->variant != kRenderStatic)
   {
-    if(W > 8u * 65535u || a.n_local_rows > 8u * 65535u)
-      return fail(ctx, TRT_E_INVALID, "trt_render: persistent variant packs tile coordinates in 16 bits (W, rows <= 524280)");
+    if(W > 8u * 65535u || a.n_local_rows > 8u * 32767u)
+      return fail(ctx, TRT_E_INVALID, "trt_render: the tile lists pack tile coordinates in 16 + 15 bits (W <= 524280, rows <= 262136)");
     const size_t n_tiles = (size_t)((W + 7) / 8) * ((a.n_local_rows + 7) / 8);
     if(int rc = grow(ctx, ctx->d_tiles, 2 * n_tiles * sizeof(uint32_t))) return rc;
     a.tiles_live  = (uint32_t*)ctx->d_tiles.p;
@@ -491,6 +491,12 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     a.min_batch = 24;
     if(const char* e = getenv("TRT_MIN_BATCH")) a.min_batch = (uint32_t)atoi(e);
     if(getenv("TRT_NO_TILE_CULL")) a.tile_cull = 0;
+    // The finer, per-tile classification costs 8 µs more at 4096² and pays when most macro tiles
+    // touch a bounding volume: the toroidal camera looks in every direction from among the
+    // geometry (inside a torus: 0.30 → 0.21 ms); for the pinhole camera the macro-level test
+    // already culls 85 % of the frame and the extra pass is a net loss (+3…8 %).
+    a.fine = camera == TRT_CAMERA_TOROIDAL ? 1u : 0u;
+    if(const char* e = getenv("TRT_FINE_CLASSIFY")) a.fine = (uint32_t)atoi(e);
     if(const char* e = getenv("TRT_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(e);  // timing ablations only
     uintptr_t bits = 0;
     const void* hp[8] = {a.hits.t, a.hits.px, a.hits.py, a.hits.pz, a.hits.nx, a.hits.ny, a.hits.nz, a.hits.id};

@@ -311,6 +311,33 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
 // caps of the sphere's silhouette and everything behind the camera.  Anything doubtful
 // (NaN, wide tiles, origin near the sphere) is LIVE.  Tiles are appended to two compact lists
 // (one wave-aggregated atomic per list per wave); order within the lists is irrelevant.
+// Approximate reciprocal / square roots for the tile classification only: its margins (≥1.6 %)
+// are four orders above their rounding (1 ulp), and nothing in the classification has to agree
+// bit for bit with anything (a tile is either provably clear or traced ray by ray).
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ v3 fnormalize(v3 a) { return scale3(a, frsq(dot3(a, a))); }
+
+// raygen() with approximate division / normalisation (classification only)
+__device__ __forceinline__ void raygen_fast(const trt_globals& g, const ToroCam& tc, uint32_t W, uint32_t H, int camera,
+                                            uint32_t x, uint32_t y, v3& origin, v3& dir)
+{
+  if(camera == TRT_CAMERA_TOROIDAL)
+  {
+    const float ca = tc.cos_a[x], sa = tc.sin_a[x], cb = tc.cos_b[y], sb = tc.sin_b[y];
+    origin = {fma_(tc.rho, ca, tc.eye[0]), tc.eye[1], fma_(tc.rho, sa, tc.eye[2])};
+    dir    = {ca * cb, sb, sa * cb};   // unit
+    return;
+  }
+  const float u = ((float)x + 0.5f) * frcp((float)W), v = ((float)y + 0.5f) * frcp((float)H);
+  origin       = mat4_mul(g.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f);
+  const v3 tgt = mat4_mul(g.projInverse, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 1.0f, 1.0f);
+  const v3 tn  = fnormalize(tgt);
+  dir          = fnormalize(mat4_mul(g.viewInverse, tn.x, tn.y, tn.z, 0.0f));
+}
+
+template <bool MARCH>
 __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs& a, uint32_t x0, uint32_t ty, uint32_t width)
 {
   const uint32_t x1 = min(x0 + width - 1, a.W - 1);
@@ -324,8 +351,7 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
   for(int i = 0; i < 5; ++i)
   {
     v3 o, d;
-    raygen(a.g, a.toro, a.W, a.H, a.camera, xs[i], ys[i], o, d);
-    d = normalize3(d);
+    raygen_fast(a.g, a.toro, a.W, a.H, a.camera, xs[i], ys[i], o, d);   // unit direction
     if(i == 0) { oc = o; dc = d; }
     else
     {
@@ -334,16 +360,16 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
       shift2 = max_(shift2, dot3(od, od));
     }
   }
-  const float theta = (a.camera == TRT_CAMERA_PINHOLE ? 1.6f : 2.0f) * sqrt_(chord2);
-  const float dO    = 1.5f * sqrt_(shift2);
+  const float theta = (a.camera == TRT_CAMERA_PINHOLE ? 1.6f : 2.0f) * fsqrt(chord2);
+  const float dO    = 1.5f * fsqrt(shift2);
   if(!(theta < 0.5f))
     return false;
   for(int i = 0; i < S.n_tori; ++i)
   {
     const v3    v  = sub3(v3{S.shade[i].cx, S.shade[i].cy, S.shade[i].cz}, oc);
     const float L2 = dot3(v, v), s = dot3(v, dc);
-    const float L  = sqrt_(L2), dl = sqrt_(max_(L2 - s * s, 0.0f));
-    const float rb = sqrt_(S.k32[i].Rb2);
+    const float L  = fsqrt(L2), dl = fsqrt(max_(L2 - s * s, 0.0f));
+    const float rb = fsqrt(S.k32[i].Rb2);
     // (1) every line of the bundle misses the bounding sphere
     if(dl - dO - (L + dO) * theta > rb * 1.015625f + 1e-5f * (L + 1.0f))
       continue;
@@ -363,7 +389,7 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
       if(disc < 0.0f) miss = true;
       else
       {
-        const float sq = sqrt_(disc), ia = 1.0f / ca;
+        const float sq = fsqrt(disc), ia = frcp(ca);
         t_lo = max_(t_lo, (-cb - sq) * ia - delta);
         t_hi = min_(t_hi, (sq - cb) * ia + delta);
       }
@@ -373,7 +399,7 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
     {
       if(abs_(dc.y) > 1e-6f)
       {
-        const float iy = 1.0f / dc.y, u0 = (-hs - ey) * iy, u1 = (hs - ey) * iy;
+        const float iy = frcp(dc.y), u0 = (-hs - ey) * iy, u1 = (hs - ey) * iy;
         t_lo = max_(t_lo, min_(u0, u1) - delta);
         t_hi = min_(t_hi, max_(u0, u1) + delta);
       }
@@ -381,7 +407,33 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
     }
     if(miss || t_lo > t_hi)
       continue;
-    return false;  // this torus may be hit by some ray of the tile (NaNs land here too)
+    // (3) the bundle passes through the bounding box: march the centre ray through [t_lo, t_hi]
+    //     with the torus' distance function dist(P) = |(ρ - R, y)| - r (1-Lipschitz).  Every point
+    //     of every ray of the bundle at arc length s lies within dev(s) = Δo + s·θ of the centre
+    //     ray's point, so while slack = dist - dev stays positive no ray touches the torus, and a
+    //     step of slack / (1 + θ) keeps it positive.  Tiles in the hole or along the silhouette
+    //     run out of slack or of steps and stay LIVE (NaNs too).
+    if(MARCH)
+    {
+      const float R = S.shade[i].R, r = fsqrt(S.k32[i].r2);
+      const float kstep = 0.9f * frcp(1.0f + theta), floor_ = 0.02f * r, pad = 1e-5f * (L + 1.0f);
+      float sArc = t_lo;
+      bool  passed = false;
+      for(int it = 0; it < 16; ++it)
+      {
+        const float px = fma_(sArc, dc.x, ex), py = fma_(sArc, dc.y, ey), pz = fma_(sArc, dc.z, ez);
+        const float e  = fsqrt(fma_(pz, pz, px * px)) - R;
+        const float dist  = fsqrt(fma_(e, e, py * py)) - r;
+        const float slack = dist - (1.02f * (dO + sArc * theta) + pad);
+        if(!(slack > floor_))
+          break;
+        sArc = fma_(slack, kstep, sArc);
+        if(sArc > t_hi) { passed = true; break; }
+      }
+      if(passed)
+        continue;
+    }
+    return false;  // this torus may be hit by some ray of the tile
   }
   return true;
 }
@@ -412,7 +464,7 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   const uint32_t mx = t % macro_x, ty = t / macro_x;
   const uint32_t tx0 = mx * kMacroTiles;
   const uint32_t ntile = valid ? min(kMacroTiles, tiles_x - tx0) : 0u;   // 8×8 tiles inside the image
-  const bool     clear = valid && a.tile_cull && tile_is_clear(scene, a, tx0 * 8, ty, kMacroTiles * 8);
+  const bool     clear = valid && a.tile_cull && tile_is_clear<false>(scene, a, tx0 * 8, ty, kMacroTiles * 8);
   const uint32_t nlive = clear ? 0u : ntile;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -447,6 +499,77 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   const uint32_t il = block_base[0] + wave_cnt[0][wave] + pre[0];
   for(uint32_t j = 0; j < nlive; ++j)
     a.tiles_live[il + j] = (tx0 + j) | (ty << 16);
+}
+
+// Second, finer classification (RenderArgs::fine): one lane per 8×8 tile; four consecutive lanes are one MACRO tile (32×8 pixels: one 128-B line
+// of every first-hit stream per row).  A macro tile whose four tiles are all clear becomes ONE
+// entry of the CLEAR list (written later with full-line dwordx4 stores); otherwise each of its
+// tiles goes to the LIVE list, a clear one with kTileMissFlag set: the listed kernel writes its
+// miss records without tracing (the other kernels ignore the flag and trace it — same result).
+// (Ordering the LIVE list heavy-tiles-first was tried: render +10 %, classify 8 → 26 µs.)
+constexpr uint32_t kTileMissFlag = 0x80000000u;   // packed entry = tx | ty << 16 | flag; ty < 2^15
+__device__ __forceinline__ uint32_t tile_x(uint32_t packed) { return packed & 0xffffu; }
+__device__ __forceinline__ uint32_t tile_y(uint32_t packed) { return (packed >> 16) & 0x7fffu; }
+
+__global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(const SceneK scene, const RenderArgs a)
+{
+  // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
+  // per list per block (a returning atomic on a shared word costs ≈11 ns under contention —
+  // MI355X_MICROARCH.md "dequeue" — so they must be rare).  Lists: 0 = LIVE, 1 = CLEAR.
+  __shared__ uint32_t wave_cnt[2][kClassifyThreads / 64];
+  __shared__ uint32_t block_base[2];
+  const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
+  const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  // The list counters are double-buffered: this frame counts in a.queue, and zeroes the set
+  // the NEXT frame will count in (no memset launch between frames; frames of one ctx are
+  // ordered by the caller, include/trt.h).
+  if(t < 2)
+    a.queue_next[t] = 0u;
+  const uint32_t m = t / kMacroTiles, j = t % kMacroTiles;      // macro tile, tile inside it
+  const uint32_t mx = m % macro_x, ty = m / macro_x;
+  const uint32_t tx = mx * kMacroTiles + j;
+  const bool     valid = ty < tiles_y && tx < tiles_x;
+  const bool     clear = valid && a.tile_cull && tile_is_clear<true>(scene, a, tx * 8, ty, 8);
+  // all four tiles of the macro tile clear (tiles outside the image count as clear)
+  uint32_t c4 = (clear || !valid) ? 1u : 0u;
+  c4 &= (uint32_t)__shfl_xor((int)c4, 1, 64);
+  c4 &= (uint32_t)__shfl_xor((int)c4, 2, 64);
+  const bool     macro_clear = c4 != 0u;
+  const uint32_t nlive  = (valid && !macro_clear) ? 1u : 0u;
+  const uint32_t nclear = (valid && macro_clear && j == 0) ? 1u : 0u;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // wave-level exclusive prefixes of the two counts
+  uint32_t pre[2] = {nlive, nclear};
+#pragma unroll
+  for(int off = 1; off < 64; off <<= 1)
+#pragma unroll
+    for(int k = 0; k < 2; ++k)
+    {
+      const uint32_t v = __shfl_up(pre[k], off, 64);
+      if(lane >= (uint32_t)off) pre[k] += v;
+    }
+  if(lane == 63) { wave_cnt[0][wave] = pre[0]; wave_cnt[1][wave] = pre[1]; }
+  pre[0] -= nlive;
+  pre[1] -= nclear;
+  __syncthreads();
+  if(threadIdx.x < 2)
+  {
+    uint32_t sum = 0;
+    for(uint32_t w = 0; w < kClassifyThreads / 64; ++w)
+    {
+      const uint32_t c = wave_cnt[threadIdx.x][w];
+      wave_cnt[threadIdx.x][w] = sum;  // exclusive prefix over the block's waves
+      sum += c;
+    }
+    block_base[threadIdx.x] = sum ? atomicAdd(&a.queue[threadIdx.x], sum) : 0u;
+  }
+  __syncthreads();
+  if(nclear)
+    a.tiles_clear[block_base[1] + wave_cnt[1][wave] + pre[1]] = tx | (ty << 16);
+  if(nlive)
+    a.tiles_live[block_base[0] + wave_cnt[0][wave] + pre[0]] = tx | (ty << 16) | (clear ? kTileMissFlag : 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -489,7 +612,7 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
   float inf, zero, one;
   asm volatile("v_mov_b32 %0, 0x7f800000\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 1.0" : "=v"(inf), "=v"(zero), "=v"(one));
   const float4 c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, one);
-  const uint32_t x0 = (packed & 0xffffu) * 8, ly = (packed >> 16) * 8 + (lane >> 3), q = lane & 7;
+  const uint32_t x0 = tile_x(packed) * 8, ly = tile_y(packed) * 8 + (lane >> 3), q = lane & 7;
   if(ly >= a.n_local_rows)
     return 0;
   const uint32_t y   = image_row(a, ly);
@@ -706,7 +829,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         if(kind == K_NONE && rank < avail)
         {
           const uint32_t within = next_in_tile + rank;
-          const uint32_t x = (cur & 0xffffu) * 8 + (within & 7), ly = (cur >> 16) * 8 + (within >> 3);
+          const uint32_t x = tile_x(cur) * 8 + (within & 7), ly = tile_y(cur) * 8 + (within >> 3);
           if(x < a.W && ly < a.n_local_rows)
           {
             px = x;
@@ -857,9 +980,22 @@ __global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES
     if(i < my_live && !(a.debug_skip & 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
-      const uint32_t x = (packed & 0xffffu) * 8 + (ln & 7), ly = (packed >> 16) * 8 + (ln >> 3);
+      const uint32_t x = tile_x(packed) * 8 + (ln & 7), ly = tile_y(packed) * 8 + (ln >> 3);
       if(x < a.W && ly < a.n_local_rows)
-        trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+      {
+        if(packed & kTileMissFlag)
+        {
+          // classified "every ray of this tile misses": the miss record of trace_pixel, no tracing
+          // (rmiss:37 → rgen:76 with attenuation 1 → rgen:87; BEF rmiss:21)
+          const size_t oi = out_index(a, x, image_row(a, ly), ly);
+          store_first_hit(a, oi, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);
+          if(a.rgba)
+            st4(a.rgba + 4 * oi, make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, 1.0f));
+          n_primary += (uint32_t)S.n_tori;
+        }
+        else
+          trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+      }
     }
   }
   if(a.debug_skip & 4u)   // experiment: all clear tiles after the traced ones
@@ -1025,10 +1161,15 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
   const uint64_t tiles = (uint64_t)((a.W + 7) / 8) * ((a.n_local_rows + 7) / 8);
   if(v == kRenderPersistent || v == kRenderListed)
   {
-    // 1. classify the tiles (one lane per tile) into the LIVE and CLEAR lists
+    // 1. classify the tiles into the LIVE and CLEAR lists (one lane per macro tile, or per 8×8 tile when a.fine)
     const uint64_t macros = (uint64_t)(((a.W + 7) / 8 + kMacroTiles - 1) / kMacroTiles) * ((a.n_local_rows + 7) / 8);
-    hipLaunchKernelGGL(tile_classify_kernel, dim3((uint32_t)((macros + kClassifyThreads - 1) / kClassifyThreads)),
-                       dim3(kClassifyThreads), 0, stream, scene, a);
+    const uint64_t lanes  = a.fine ? macros * kMacroTiles : macros;
+    if(a.fine)
+      hipLaunchKernelGGL(tile_classify_fine_kernel, dim3((uint32_t)((lanes + kClassifyThreads - 1) / kClassifyThreads)),
+                         dim3(kClassifyThreads), 0, stream, scene, a);
+    else
+      hipLaunchKernelGGL(tile_classify_kernel, dim3((uint32_t)((lanes + kClassifyThreads - 1) / kClassifyThreads)),
+                         dim3(kClassifyThreads), 0, stream, scene, a);
     // 2. resident grid: kPersistentBlocksPerCU blocks of 4 waves per CU, never more waves than tiles
     uint64_t cap = (uint64_t)n_cus * kPersistentBlocksPerCU;
     if(const char* e = getenv("TRT_PERSIST_BLOCKS")) cap = (uint64_t)atoll(e);

@@ -32,6 +32,7 @@ struct RenderArgs {
   uint32_t*           tiles_clear;  // tiles whose every pixel misses every bounding sphere
   uint32_t            min_batch;    // persistent kernel: lanes needed to run a shader/refill round (default 24)
   uint32_t            tile_cull;    // 0: classify every tile as LIVE
+  uint32_t            fine;         // 1: classify per 8×8 tile with the distance-function march (toroidal camera)
   uint32_t            debug_skip;   // diagnostics (TRT_DEBUG_SKIP): 1 = skip clear tiles, 2 = skip traced tiles
   uint32_t            vec4_ok;      // W % 4 == 0 and all first-hit streams 16-B aligned: dwordx4 clears
 };
