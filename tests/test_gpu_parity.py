@@ -415,6 +415,20 @@ def test_tile_classification_is_conservative(tr, oracle, cam, variant, fine, sce
         tr.set_render_variant("listed")
 
 
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (8, 8), (33, 9), (5, 64), (129, 17)])
+def test_render_ragged_sizes(tr, oracle, size, variant):
+    """Frames smaller than a tile, than a macro tile, and not multiples of either, both cameras."""
+    W, H = size
+    tr.set_render_variant(variant)
+    try:
+        for name in ("mirror_d5", "toroidal_interior"):
+            sc, g, pc, cam = RENDERS[name](W, H)
+            check_render(tr, oracle, sc, g, pc, W, H, cam)
+    finally:
+        tr.set_render_variant("listed")
+
+
 @pytest.mark.parametrize("fine", [0, 1])
 @pytest.mark.parametrize("name", ["toroidal_interior", "toroidal_survey", "toroidal_tilted"])
 def test_toroidal_classification_levels(tr, oracle, name, fine):
