@@ -445,6 +445,47 @@ def test_toroidal_classification_levels(tr, oracle, name, fine):
         tr.enable_stats(False)
 
 
+def random_case(seed):
+    """A seeded random scene + camera + push constants (both camera models, 1-8 tori that may
+    intersect, every material kind, both light types)."""
+    rng = np.random.default_rng(1000 + seed)
+    mats = [camera.MIRROR, camera.PLASTIC, camera.MATTE, camera.FLAT]
+    n = int(rng.integers(1, 9))
+    tori = []
+    for _ in range(n):
+        R = float(rng.uniform(0.5, 3.0))
+        tori.append((tuple(rng.uniform(-2.0, 2.0, 3)), R, float(rng.uniform(0.05, 0.9) * R), int(rng.integers(0, 4))))
+    sc = abi.Scene(tori, mats)
+    W, H = int(rng.integers(5, 30)) * 8 + int(rng.integers(0, 8)), int(rng.integers(5, 24)) * 8 + int(rng.integers(0, 8))
+    toroidal = bool(rng.integers(0, 2))
+    eye = rng.normal(size=3)
+    eye = tuple(eye / np.linalg.norm(eye) * rng.uniform(0.0 if toroidal else 2.0, 8.0))
+    center = tuple(rng.uniform(-1.0, 1.0, 3) + (np.array([6.0, 0.0, 0.0]) if toroidal else 0.0))
+    g = camera.globals_for(eye, center, W, H, fov_deg=float(rng.uniform(20.0, 110.0)))
+    pc = abi.make_push(clear=tuple(rng.uniform(0.0, 1.0, 3)) + (1.0,), light_pos=tuple(rng.uniform(-12.0, 16.0, 3)),
+                       light_intensity=float(rng.uniform(10.0, 200.0)), light_type=int(rng.integers(0, 2)),
+                       max_depth=int(rng.integers(1, 7)), rho=float(rng.uniform(0.5, 5.0)))
+    return sc, g, pc, W, H, int(toroidal)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes(tr, oracle, seed):
+    """Fuzz: 24 seeded random scenes/cameras through every render variant and both classification
+    levels — first-hit records bit-exact, query counts identical, colours within tolerance."""
+    sc, g, pc, W, H, cam = random_case(seed)
+    for variant, fine in (("listed", 0), ("listed", 1), ("persistent", 1), ("static", 0)):
+        tr.set_render_variant(variant)
+        tr.enable_stats(True)
+        os.environ["TRT_FINE_CLASSIFY"] = str(fine)
+        try:
+            _, _, wstats = check_render(tr, oracle, sc, g, pc, W, H, cam)
+            assert tr.stats() == wstats, (variant, fine)
+        finally:
+            os.environ.pop("TRT_FINE_CLASSIFY", None)
+            tr.enable_stats(False)
+            tr.set_render_variant("listed")
+
+
 def test_post_pass_bit_exact(tr, oracle):
     """trt_post_dev (tonemap of post.frag) — float and UNORM8 outputs bit for bit equal to the
     oracle: the exp2/log2 polynomials use only correctly rounded operations."""
