@@ -40,8 +40,10 @@
 #define FMIN fminf
 #define FABS fabsf
 #define TRT_DK_TOL 0.0009765625f /* 2^-10 */
+#define TRT_USTOP 0.000244140625f /* 2^-12 */
 #include "trt_solve.inc"
 #undef TRT_DK_TOL
+#undef TRT_USTOP
 #undef REAL
 #undef SUF
 #undef FMA
@@ -58,8 +60,10 @@
 #define FMIN fmin
 #define FABS fabs
 #define TRT_DK_TOL 2.384185791015625e-07 /* 2^-22 */
+#define TRT_USTOP 5.9604644775390625e-08 /* 2^-24 */
 #include "trt_solve.inc"
 #undef TRT_DK_TOL
+#undef TRT_USTOP
 #undef REAL
 #undef SUF
 #undef FMA

@@ -130,6 +130,10 @@ __device__ __forceinline__ void stage_scene(SceneK* lds, const SceneK& arg)
 // pieces/modes.
 enum : int { M_FWD = 0, M_BWD = 1, M_PROBE = 2, M_END = 3, M_DONE = 4 };
 constexpr int kNewtonCap = 48;
+// Newton's early stop, as a fraction of the piece: 2^-12 (FP32), 2^-24 (FP64)
+template <class Real> struct StepStop;
+template <> struct StepStop<float> { static constexpr float v = 0.000244140625f; };
+template <> struct StepStop<double> { static constexpr double v = 5.9604644775390625e-08; };
 
 // One ray-vs-torus test as a resumable state machine: setup() does T1 (returns false when the
 // bounding sphere / parameter window culls the ray), every step() evaluates (f, f') once and
@@ -145,6 +149,7 @@ struct TorusTest {
   Real A, B, xe, root;
   int  sigma, sref, it, mode;
   bool split, found;
+  static constexpr Real kStepStop = StepStop<Real>::v;
 
   __device__ __forceinline__ bool setup(Real ox, Real oy, Real oz, Real dx_, Real dy_, Real dz_,
                                         Real dd, Real inv_dd, Real tmin, Real tmax,
@@ -255,22 +260,30 @@ struct TorusTest {
     const bool isB    = mBwd || probe_ok;
     const bool cap    = (isF || isB) && it2 == kNewtonCap;
     const Real sdx    = sigma2 > 0 ? de : -de;
-    const Real xn     = u - fe / de;
+    const Real st     = fe / de;
+    const Real xn     = u - st;
+    // Newton stops once a step is below 2^-12 (FP32; 2^-24 FP64) of the piece: the iterate is
+    // then within ~step²/r of the root, far inside the capture range of finish()'s geometric
+    // step — the one or two evaluations that used to confirm the fixed point are not spent
+    const bool small  = abs_(st) <= (B2 - A2) * kStepStop;
     const bool f_no   = isF && !cap && (!(sdx < Real(0)) || !(xn < B2));  // no root in [u,B]
     const bool f_cv   = isF && !cap && !f_no && xn == u;
+    const bool f_es   = isF && !cap && !f_no && xn != u && small;
     const bool b_stop = (zer || sfe != sref2) || !(sdx > Real(0));
     const bool b_left = !(xn > A2);
     const bool b_hitx = isB && !cap && (b_stop || (!b_left && xn == u));
     const bool b_hitA = isB && !cap && !b_stop && b_left;
-    const bool go     = (isF && !cap && !f_no && !f_cv) || (isB && !cap && !b_stop && !b_left && xn != u);
+    const bool b_es   = isB && !cap && !b_stop && !b_left && xn != u && small;
+    const bool go     = (isF && !cap && !f_no && !f_cv && !f_es) || (isB && !cap && !b_stop && !b_left && xn != u && !b_es);
 
     const bool hit_x = e_hit || f_flip || cap || f_cv || b_hitx;
+    const bool hit_n = f_es || b_es;   // accepted at the new iterate
     // a forward run that proves "no root" in the LAST piece decides the test: nothing is
     // evaluated at hi any more (that evaluation carried no information)
     const bool last_no = f_no && !(B2 < hi);
-    const bool done  = (leave && !more) || hit_x || b_hitA || last_no;
-    found = hit_x || b_hitA;
-    root  = b_hitA ? A2 : u;
+    const bool done  = (leave && !more) || hit_x || hit_n || b_hitA || last_no;
+    found = hit_x || hit_n || b_hitA;
+    root  = b_hitA ? A2 : (hit_n ? xn : u);
     A = A2; B = B2; sigma = sigma2; sref = sref2; it = it2;
     xe   = (e_prb || f_no) ? B2 : (go ? xn : u);
     mode = done ? M_DONE : (e_prb ? M_PROBE : (f_no ? M_END : (isF ? M_FWD : M_BWD)));
@@ -293,18 +306,21 @@ struct TorusTest {
     const int  it2  = it + 1;
     const bool cap  = it2 == kNewtonCap;
     const Real sdx  = sigma > 0 ? de : -de;
-    const Real xn   = u - fe / de;
-    // forward: flip -> hit, cap -> hit, slope/range -> END, converged -> hit
-    // backward: cap -> hit, flip/slope -> hit, left of A -> hit(A), converged -> hit
+    const Real st   = fe / de;
+    const Real xn   = u - st;
+    const bool small = abs_(st) <= (B - A) * kStepStop;
+    // forward: flip -> hit, cap -> hit, slope/range -> END, converged -> hit, small step -> hit(xn)
+    // backward: cap -> hit, flip/slope -> hit, left of A -> hit(A), converged -> hit, small step -> hit(xn)
     const bool f_no   = fwd && !flip && !cap && (!(sdx < Real(0)) || !(xn < B));
     const bool b_stop = flip || !(sdx > Real(0));
     const bool b_hitA = !fwd && !cap && !b_stop && !(xn > A);
     const bool hit_x  = fwd ? (flip || cap || (!f_no && xn == u))
                             : (cap || b_stop || (!b_hitA && xn == u));
+    const bool hit_n  = !hit_x && !f_no && !b_hitA && small;
     const bool last_no = f_no && !(B < hi);   // "no root" in the last piece: the test is a miss
-    const bool done   = hit_x || b_hitA || last_no;
-    found = hit_x || b_hitA;
-    root  = b_hitA ? A : u;
+    const bool done   = hit_x || hit_n || b_hitA || last_no;
+    found = hit_x || hit_n || b_hitA;
+    root  = b_hitA ? A : (hit_n ? xn : u);
     it    = it2;
     xe    = f_no ? B : (done ? u : xn);
     mode  = done ? M_DONE : (f_no ? M_END : mode);

@@ -234,7 +234,13 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
       if(depth == 0)
       {
         store_first_hit(a, oi, t, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);  // BEF rmiss:21
-        if(rd) st4(rd, make_float4(0.0f, 0.0f, 0.0f, 1.0f));
+        if(rd)
+        {
+          // materialised here: hoisted out of the tile loop this constant vector gets spilled
+          float z, o1;
+          asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 1.0" : "=v"(z), "=v"(o1));
+          st4(rd, make_float4(z, z, z, o1));
+        }
       }
     }
     else
