@@ -1189,6 +1189,7 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       if(const char* e = getenv("TRT_LISTED_BLOCKS")) lcap = (uint64_t)atoll(e);
       uint32_t bthreads = 256;
       if(const char* e = getenv("TRT_LISTED_THREADS")) bthreads = (uint32_t)atoi(e);
+      if(bthreads != 64 && bthreads != 128) bthreads = 256;   // __launch_bounds__(256): nothing larger may be launched
       const uint32_t wpb = bthreads / 64;
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
 #define TRT_LAUNCH_LISTED(REAL, DK_)                                                                                   \
