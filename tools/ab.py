@@ -13,6 +13,8 @@ ap.add_argument("--depth", type=int, default=5)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--frames", type=int, default=10)
 ap.add_argument("--center", default="0,0,0")
+ap.add_argument("--eye", default="0,1.5,-4")
+ap.add_argument("--fov", type=float, default=60.0)
 ap.add_argument("--scene", default="single")
 ap.add_argument("--f64", action="store_true")
 ap.add_argument("--hits", default="tpn")
@@ -21,7 +23,7 @@ a = ap.parse_args()
 W = H = a.size
 dev = torch.device("cuda:0")
 sc = camera.single_torus_scene() if a.scene == "single" else camera.nested_tori_scene()
-g = camera.globals_for((0.0, 1.5, -4.0), tuple(float(v) for v in a.center.split(",")), W, H)
+g = camera.globals_for(tuple(float(v) for v in a.eye.split(",")), tuple(float(v) for v in a.center.split(",")), W, H, fov_deg=a.fov)
 pc = camera.baseline_push(a.depth)
 tr = Tracer(0)
 if a.f64:
