@@ -57,11 +57,14 @@ enum {
 
 /* ---- root solver and its precision ---------------------------- */
 /* Default: the Fourier–Newton walk on the depressed quartic, FP32; _F64 = BASELINE config 4
- * ("FP64 root solve", FP32 I/O).  _DK_* select the Durand–Kerner iteration north_star names
- * (fixed sweep count, complex arithmetic): same interface and outputs, ≈10x the cost and a
- * tolerance-based real-root test — kept as a measured alternative.  The
- * persistent render variant implements the default solver only. */
-enum { TRT_SOLVE_F32 = 0, TRT_SOLVE_F64 = 1, TRT_SOLVE_DK_F32 = 2, TRT_SOLVE_DK_F64 = 3 };
+ * ("FP64 root solve", FP32 I/O).  _DK_* and _FERRARI_* select the two solvers north_star names —
+ * the Durand–Kerner iteration (fixed sweep count, complex arithmetic) and Ferrari's factorisation
+ * (resolvent cubic by a fixed-count Newton iteration instead of cbrt/acos): same interface and
+ * outputs, several times the cost and a tolerance- / discriminant-based real-root test — kept as
+ * measured alternatives.  The persistent render variant implements the default
+ * solver only. */
+enum { TRT_SOLVE_F32 = 0, TRT_SOLVE_F64 = 1, TRT_SOLVE_DK_F32 = 2, TRT_SOLVE_DK_F64 = 3,
+       TRT_SOLVE_FERRARI_F32 = 4, TRT_SOLVE_FERRARI_F64 = 5 };
 
 /* ---- uniform / push-constant blocks, byte-for-byte the reference's host structs ---- */
 

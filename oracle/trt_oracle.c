@@ -110,7 +110,7 @@ typedef struct {
   int          nmat;
   trt_material mat[TRT_MAX_MATERIALS];
   int          f64;
-  int          dk;   /* 1: Durand–Kerner root solve instead of the Fourier–Newton walk */
+  int          dk;   /* 0: Fourier–Newton walk; alternative root solvers: 1 Durand–Kerner, 2 Ferrari */
   int          order[TRT_MAX_TORI]; /* test order: descending bounding radius R + r, ties by index */
 } scene_t;
 
@@ -121,8 +121,9 @@ static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
     return TRT_E_SCENE;
   out->n    = (int)s->n_tori;
   out->nmat = (int)s->n_materials;
-  out->f64  = precision == TRT_SOLVE_F64 || precision == TRT_SOLVE_DK_F64;
-  out->dk   = precision == TRT_SOLVE_DK_F32 || precision == TRT_SOLVE_DK_F64;
+  out->f64  = precision == TRT_SOLVE_F64 || precision == TRT_SOLVE_DK_F64 || precision == TRT_SOLVE_FERRARI_F64;
+  out->dk   = (precision == TRT_SOLVE_DK_F32 || precision == TRT_SOLVE_DK_F64) ? 1
+              : (precision == TRT_SOLVE_FERRARI_F32 || precision == TRT_SOLVE_FERRARI_F64) ? 2 : 0;
   for(int i = 0; i < out->n; ++i)
   {
     const trt_torus* t = &s->tori[i];
@@ -589,8 +590,9 @@ int oracle_torus_first_hit(const trt_torus* T, const float* o, const float* d, f
                            float tmax, int precision, double* t_out, int* evals)
 {
   int ne = 0, hit;
-  const int dk = precision == TRT_SOLVE_DK_F32 || precision == TRT_SOLVE_DK_F64;
-  if(precision == TRT_SOLVE_F64 || precision == TRT_SOLVE_DK_F64)
+  const int dk = (precision == TRT_SOLVE_DK_F32 || precision == TRT_SOLVE_DK_F64) ? 1
+                 : (precision == TRT_SOLVE_FERRARI_F32 || precision == TRT_SOLVE_FERRARI_F64) ? 2 : 0;
+  if(precision == TRT_SOLVE_F64 || precision == TRT_SOLVE_DK_F64 || precision == TRT_SOLVE_FERRARI_F64)
   {
     torus_k_f64 k;
     torus_prepare_f64(T, &k);

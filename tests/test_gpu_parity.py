@@ -43,8 +43,9 @@ SCENES = {
 
 
 @pytest.mark.parametrize("scene", list(SCENES))
-@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64, abi.TRT_SOLVE_DK_F32, abi.TRT_SOLVE_DK_F64],
-                         ids=["f32", "f64", "dk32", "dk64"])
+@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64, abi.TRT_SOLVE_DK_F32, abi.TRT_SOLVE_DK_F64,
+                                       abi.TRT_SOLVE_FERRARI_F32, abi.TRT_SOLVE_FERRARI_F64],
+                         ids=["f32", "f64", "dk32", "dk64", "ferrari32", "ferrari64"])
 def test_trace_bit_exact_vs_oracle(tr, oracle, scene, precision):
     sc = SCENES[scene]()
     o, d = seeded_rays(100_003, 1234, center=sc.tori_list()[0][0], box=5.0, reach=2.4)
@@ -184,11 +185,12 @@ def test_render_fp64_nested(tr, oracle, variant):
 
 
 @pytest.mark.parametrize("variant", ["static", "listed"])
-@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_DK_F32, abi.TRT_SOLVE_DK_F64], ids=["dk32", "dk64"])
+@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_DK_F32, abi.TRT_SOLVE_DK_F64, abi.TRT_SOLVE_FERRARI_F32,
+                                       abi.TRT_SOLVE_FERRARI_F64], ids=["dk32", "dk64", "ferrari32", "ferrari64"])
 @pytest.mark.parametrize("name", ["mirror_d5", "nested_d5", "toroidal_interior"])
 def test_render_durand_kerner(tr, oracle, name, precision, variant):
-    """The Durand–Kerner solver (north_star's T2) behind the same render path: bit-exact first-hit
-    record and query counts against the oracle's restatement of the same iteration."""
+    """The two solvers north_star names for T2 (Durand–Kerner, Ferrari) behind the same render
+    path: bit-exact first-hit record and query counts against the oracle's restatement of each."""
     W, H = 136, 104
     sc, g, pc, cam = RENDERS[name](W, H)
     tr.set_solver(precision)

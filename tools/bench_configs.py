@@ -89,6 +89,10 @@ render_case("C3 with Durand-Kerner FP32", camera.single_torus_scene(), camera.ba
             variants=("listed",), solver=abi.TRT_SOLVE_DK_F32)
 render_case("C3 with Durand-Kerner FP64", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W,
             variants=("listed",), solver=abi.TRT_SOLVE_DK_F64)
+render_case("C3 with Ferrari FP32", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W,
+            variants=("listed",), solver=abi.TRT_SOLVE_FERRARI_F32)
+render_case("C3 with Ferrari FP64", camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W,
+            variants=("listed",), solver=abi.TRT_SOLVE_FERRARI_F64)
 render_case("C4 8 nested tori, FP64 solve", camera.nested_tori_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W, f64=True)
 render_case("C4' 8 nested tori, FP32 solve", camera.nested_tori_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), W, W)
 pc = camera.baseline_push(5); pc.rho = 4.0

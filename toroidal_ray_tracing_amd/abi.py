@@ -17,6 +17,7 @@ TRT_MAX_TORI = 8
 TRT_MAX_MATERIALS = 8
 TRT_CAMERA_PINHOLE, TRT_CAMERA_TOROIDAL = 0, 1
 TRT_SOLVE_F32, TRT_SOLVE_F64, TRT_SOLVE_DK_F32, TRT_SOLVE_DK_F64 = 0, 1, 2, 3
+TRT_SOLVE_FERRARI_F32, TRT_SOLVE_FERRARI_F64 = 4, 5
 
 ERROR_NAMES = {
     TRT_E_INVALID: "TRT_E_INVALID", TRT_E_NO_DEVICE: "TRT_E_NO_DEVICE", TRT_E_HIP: "TRT_E_HIP",

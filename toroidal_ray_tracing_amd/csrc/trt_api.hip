@@ -118,8 +118,9 @@ int build_scene(trt_ctx* ctx, const trt_scene* s, SceneK& out)
   std::memset(&out, 0, sizeof out);
   out.n_tori = (int)s->n_tori;
   out.n_mat  = (int)s->n_materials;
-  out.f64    = ctx->precision == TRT_SOLVE_F64 || ctx->precision == TRT_SOLVE_DK_F64;
-  out.dk     = ctx->precision == TRT_SOLVE_DK_F32 || ctx->precision == TRT_SOLVE_DK_F64;
+  out.f64    = ctx->precision == TRT_SOLVE_F64 || ctx->precision == TRT_SOLVE_DK_F64 || ctx->precision == TRT_SOLVE_FERRARI_F64;
+  out.dk     = (ctx->precision == TRT_SOLVE_DK_F32 || ctx->precision == TRT_SOLVE_DK_F64) ? 1
+               : (ctx->precision == TRT_SOLVE_FERRARI_F32 || ctx->precision == TRT_SOLVE_FERRARI_F64) ? 2 : 0;
   for(uint32_t i = 0; i < s->n_tori; ++i)
   {
     const trt_torus& t = s->tori[i];
@@ -301,8 +302,8 @@ extern "C" void trt_destroy(trt_ctx* ctx)
 extern "C" int trt_set_solver(trt_ctx* ctx, int precision)
 {
   if(!ctx) return TRT_E_INVALID;
-  if(precision < TRT_SOLVE_F32 || precision > TRT_SOLVE_DK_F64)
-    return fail(ctx, TRT_E_INVALID, "trt_set_solver: %d is not one of TRT_SOLVE_F32, _F64, _DK_F32, _DK_F64", precision);
+  if(precision < TRT_SOLVE_F32 || precision > TRT_SOLVE_FERRARI_F64)
+    return fail(ctx, TRT_E_INVALID, "trt_set_solver: %d is not one of the TRT_SOLVE_* constants", precision);
   ctx->precision = precision;
   return TRT_OK;
 }
@@ -477,7 +478,7 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
   }
   if(ctx->variant == kRenderPersistent && S.dk)
     return fail(ctx, TRT_E_INVALID, "trt_render: the persistent variant implements the default solver only; "
-                                    "use the listed or static variant with TRT_SOLVE_DK_*");
+                                    "use the listed or static variant with TRT_SOLVE_DK_* / TRT_SOLVE_FERRARI_*");
   if(ctx->variant != kRenderStatic)
   {
     if(W > 8u * 65535u || a.n_local_rows > 8u * 32767u)

@@ -88,7 +88,7 @@ struct SceneK {
   int            n_tori;
   int            n_mat;
   int            f64;   // 1: FP64 root solve (BASELINE config 4), FP32 I/O
-  int            dk;    // 1: Durand–Kerner root solve (TRT_SOLVE_DK_*), 0: Fourier–Newton walk
+  int            dk;    // 0: Fourier–Newton walk; alternative root solvers: 1 Durand–Kerner, 2 Ferrari
   int            order[TRT_MAX_TORI];  // test order: descending bounding radius R + r, ties by index
   TorusK<float>  k32[TRT_MAX_TORI];
   TorusK<double> k64[TRT_MAX_TORI];
@@ -403,6 +403,76 @@ struct TorusTest {
     mode  = M_DONE;
   }
 
+  // T2, second alternative solver (TRT_SOLVE_FERRARI_*): Ferrari's factorisation of the monic
+  // depressed quartic into (u² - σu + e + h)(u² + σu + e - h), σ = sqrt(2m), e = p/2 + m,
+  // h = sign(q)·sqrt(m² + pm + (p² - 4s)/4), m >= 0 a root of the resolvent cubic
+  // m³ + pm² + ((p² - 4s)/4)m - q²/8 — bracketed by [0, Cauchy bound], narrowed by a FIXED number
+  // of bisections (every lane the same trip count) and two guarded Newton steps, i.e. without the
+  // cbrt/acos of the textbook form, only + - * / sqrt fma (bit for bit the CPU restatement of
+  // tests/).  Candidates are polished and selected exactly as in solve_dk().
+  __device__ __forceinline__ void solve_ferrari(Real inv_dd, Real Rb2)
+  {
+    constexpr int  kSteps = sizeof(Real) == 4 ? 40 : 72;
+    constexpr Real kTol = sizeof(Real) == 4 ? Real(0.0009765625) : Real(2.384185791015625e-07);
+    const Real iA4 = inv_dd * inv_dd;
+    const Real p = P2 * iA4, q = Q1 * iA4, s = S0 * iA4;
+    const Real sc  = sqrt_(Rb2 * inv_dd);
+    const Real tol = kTol * sc;
+    const Real lo  = A;   // setup() leaves the window start in A
+    const Real c1  = fma_(p, p, Real(-4) * s) * Real(0.25);
+    const Real c0  = (q * q) * Real(-0.125);
+    Real mlo = Real(0), mhi = Real(1) + max_(abs_(p), max_(abs_(c1), abs_(c0)));
+#pragma unroll 1
+    for(int i = 0; i < kSteps; ++i)
+    {
+      const Real mid = Real(0.5) * (mlo + mhi);
+      const Real r   = fma_(fma_(mid + p, mid, c1), mid, c0);
+      if(r > Real(0)) mhi = mid;
+      else mlo = mid;
+    }
+    Real m = Real(0.5) * (mlo + mhi);
+#pragma unroll
+    for(int i = 0; i < 2; ++i)
+    {
+      const Real r  = fma_(fma_(m + p, m, c1), m, c0);
+      const Real dr = fma_(fma_(Real(3), m, p + p), m, c1);
+      const Real mn = m - r / dr;
+      if(dr > Real(0) && mn >= mlo && mn <= mhi)
+        m = mn;
+    }
+    const Real sg = sqrt_(m + m);
+    const Real h2 = fma_(m + p, m, c1);
+    const Real h  = (q < Real(0) ? Real(-1) : Real(1)) * sqrt_(max_(h2, Real(0)));
+    const Real e  = fma_(Real(0.5), p, m);
+    const Real d1 = fma_(Real(-4), e + h, sg * sg), d2 = fma_(Real(-4), e - h, sg * sg);
+    const Real w1 = sqrt_(max_(d1, Real(0))), w2 = sqrt_(max_(d2, Real(0)));
+    const Real cand[4] = {Real(0.5) * (sg - w1), Real(0.5) * (sg + w1), Real(0.5) * (-sg - w2), Real(0.5) * (-sg + w2)};
+    const bool ok[4]   = {d1 >= Real(0), d1 >= Real(0), d2 >= Real(0), d2 >= Real(0)};
+    bool f = false;
+    Real best = Real(0);
+    const Real A4x4 = Real(4) * A4, P2x2 = Real(2) * P2;
+#pragma unroll
+    for(int k = 0; k < 4; ++k)
+    {
+      if(!ok[k])
+        continue;
+      Real u = cand[k];
+#pragma unroll
+      for(int n = 0; n < 2; ++n)
+      {
+        const Real e1 = fma_(A4 * u, u, P2), e2 = fma_(e1, u, Q1), fu = fma_(e2, u, S0);
+        const Real g1 = fma_(A4x4 * u, u, P2x2), du = fma_(g1, u, Q1);
+        const Real st = fu / du;
+        if(abs_(st) <= tol)
+          u = u - st;
+      }
+      if(u >= lo && u <= hi && (!f || u < best)) { best = u; f = true; }
+    }
+    found = f;
+    root  = best;
+    mode  = M_DONE;
+  }
+
   // T2b: one Newton step on g(u) = (ρ-R)² + py² - r², whose rounding error scales with r²
   // instead of R⁴ (a step above r/32 — grazing, g' ≈ 0 — is discarded); then t = u + tc and
   // the open-interval test of the closest-hit query.
@@ -432,13 +502,16 @@ struct TorusTest {
 template <class Real, bool DK = false>
 __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
                                                 Real dz_, Real dd, Real inv_dd, Real tmin, Real tmax,
-                                                const TorusK<Real>& T, Real& t_out)
+                                                const TorusK<Real>& T, Real& t_out, int alt = 1)
 {
   TorusTest<Real> q;
   if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))
     return false;
   if(DK)
-    q.solve_dk(inv_dd, T.Rb2);
+  {
+    if(alt == 2) q.solve_ferrari(inv_dd, T.Rb2);   // wave-uniform: the scene's solver
+    else q.solve_dk(inv_dd, T.Rb2);
+  }
   else
   {
     // per trip: the cheap iteration-only step when every running lane of the wave is iterating
@@ -489,7 +562,7 @@ __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Rea
 {
   Real tt;
   if(!torus_first_hit<Real, DK>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.dd, r.inv_dd, r.tmin, (Real)tmax,
-                                torus_k<Real>(S, i), tt))
+                                torus_k<Real>(S, i), tt, S.dk))
     return false;
   return round_t(tt, tmin, tmax, t);
 }
