@@ -100,6 +100,7 @@ render_case("toroidal camera, interior R=6", camera.single_torus_scene(R=6.0, r=
             camera.toroidal_camera(W, W), pc, W, W, cam=1)
 n = 4096 * 4096
 img = torch.rand(n, 4, device=dev)
+img[:, 3] = 1.0   # a rendered frame: alpha is 1 (rgen:87)
 o8 = torch.empty(n, 4, dtype=torch.uint8, device=dev)
 of = torch.empty(n, 4, device=dev)
 ms = timeit(lambda: tr.post_dev(img.data_ptr(), n, 0, o8.data_ptr(), stream=s.cuda_stream))
