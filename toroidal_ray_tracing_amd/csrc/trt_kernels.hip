@@ -1149,7 +1149,9 @@ hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp
                         const float* clear, float point_size, unsigned long long* keys, float* rgba, int n_cus,
                         hipStream_t stream)
 {
-  const uint64_t npx = (uint64_t)W * H, cap = (uint64_t)n_cus * 16;
+  uint64_t npx = (uint64_t)W * H, cap = (uint64_t)n_cus * 16;
+  if(const char* e = getenv("TRT_SPLAT_BLOCKS_PER_CU")) cap = (uint64_t)n_cus * (uint64_t)atoll(e);
+  if(cap == 0) cap = 1;
   auto grid = [&](uint64_t n) { const uint64_t w = (n + 255) / 256; return dim3((uint32_t)(w < cap ? (w ? w : 1) : cap)); };
   hipLaunchKernelGGL(splat_clear_kernel, grid(npx), dim3(256), 0, stream, keys, npx);
   if(n_points)
