@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         else if(depth == 0) ++n_primary;
         else ++n_bounce;
         // closest-hit queries end the interval of every later test at the closest hit so far
-        if(tst.setup(rk.ox, rk.oy, rk.oz, rk.dx, rk.dy, rk.dz, rk.dd, rk.inv_dd, rk.tmin,
+        if(tst.setup((Real)rk.ox, (Real)rk.oy, (Real)rk.oz, (Real)rk.dx, (Real)rk.dy, (Real)rk.dz, rk.dd, rk.inv_dd, (Real)rk.tmin,
                      (Real)(kind == K_CLOSEST ? min_(q_tmax, best_t) : q_tmax), torus_k<Real>(S, S.order[ti])))
           inflight = true;
         else
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
       Real  tt;
       float t;
       const float tm = kind == K_CLOSEST ? min_(q_tmax, best_t) : q_tmax;   // the interval setup() used
-      if(tst.finish(rk.dx, rk.dy, rk.dz, rk.tmin, (Real)tm, torus_k<Real>(S, S.order[ti]), tt)
+      if(tst.finish((Real)rk.dx, (Real)rk.dy, (Real)rk.dz, (Real)rk.tmin, (Real)tm, torus_k<Real>(S, S.order[ti]), tt)
          && round_t(tt, kTMin, tm, t))
       {
         if(kind == K_SHADOW) shadow_hit = true;
@@ -942,8 +942,11 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 #ifndef TRT_LISTED_WAVES
 #define TRT_LISTED_WAVES 5
 #endif
+#ifndef TRT_LISTED_WAVES_F64
+#define TRT_LISTED_WAVES_F64 4
+#endif
 template <class Real, bool STATS, bool DK>
-__global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES : 3)) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
+__global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64)) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
 {
   __shared__ SceneK     S;
   __shared__ RenderArgs A_lds;
