@@ -175,6 +175,22 @@ def main():
     px_per_launch = frame.local_pixels
     achieved = BYTES_PER_PIXEL * px_per_launch / (kern_ms * 1e-3) / 1e9
 
+    # N > 1, diagnostics only (outside the timed region): the collective alone, so that the line shows
+    # what binds the step — the rank-local render (roofline.kernel_ms) or replicating the framebuffer
+    gather_ms = None
+    if world > 1 and frame.gather:
+        try:
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            g0.record(stream)
+            for _ in range(5):
+                dist.all_gather_into_tensor(frame.gathered[0], frame.sends[0])
+            g1.record(stream)
+            torch.cuda.synchronize()
+            gather_ms = g0.elapsed_time(g1) / 5
+        except Exception as e:  # never let a diagnostic break the benchmark line
+            print(f"[bench] gather timing skipped: {e}", file=sys.stderr)
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
     if os.path.exists(tpath):
@@ -196,6 +212,7 @@ def main():
                        "tests_per_frame": {"primary": n_primary, "bounce": n_bounce, "shadow": n_shadow},
                        "tiling": frame.describe()},
             "total_tests_per_s": a.steps * (n_primary + n_bounce + n_shadow) / dt,
+            "gather_ms": gather_ms,
             "target_primary_tests_per_s": 2.0e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
