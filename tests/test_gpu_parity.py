@@ -344,32 +344,37 @@ def test_trace_dev_full_size_matches_render(tr):
 
 @pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
 @pytest.mark.parametrize("parts,group", [(2, 8), (4, 8), (3, 4), (8, 8)])
-def test_tiled_render_matches_full(tr, variant, parts, group):
+@pytest.mark.parametrize("scene_cam", ["pinhole", "toroidal"])
+def test_tiled_render_matches_full(tr, variant, parts, group, scene_cam):
     """trt_render_tiled_dev: every part renders its interleaved row groups into a compact
     buffer; stacking + de-interleaving the parts reproduces the full-frame render bit for bit
-    (this is what each rank does before the RCCL all-gather)."""
+    (this is what each rank does before the RCCL all-gather).  The toroidal case runs the
+    per-tile classification level on interleaved rows."""
     import torch
     from toroidal_ray_tracing_amd import distributed as trtd
     W, H = 120, parts * group * 5
-    sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
+    if scene_cam == "pinhole":
+        sc, g, pc, cam = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(5), 0
+    else:
+        sc, g, pc, cam = RENDERS["toroidal_interior"](W, H)
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     tr.set_render_variant(variant)
     try:
         full = torch.zeros(H, W, 4, device=dev)
         t_full = torch.zeros(H * W, device=dev)
-        tr.render_dev(sc, g, pc, W, H, full.data_ptr(), hit_ptrs={"t": t_full.data_ptr()}, stream=s)
+        tr.render_dev(sc, g, pc, W, H, full.data_ptr(), camera=cam, hit_ptrs={"t": t_full.data_ptr()}, stream=s)
         gathered = torch.zeros(parts, H // parts, W, 4, device=dev)
         t_parts = torch.zeros(parts, (H // parts) * W, device=dev)
         for p in range(parts):
             tiling = abi.trt_tiling(group, parts, p, 1)
             assert tr.tiling_rows(tiling, H) == H // parts
-            tr.render_tiled_dev(sc, g, pc, W, H, tiling, gathered[p].data_ptr(),
+            tr.render_tiled_dev(sc, g, pc, W, H, tiling, gathered[p].data_ptr(), camera=cam,
                                 hit_ptrs={"t": t_parts[p].data_ptr()}, stream=s)
         # non-compact: parts write straight into one full-frame buffer
         direct = torch.zeros(H, W, 4, device=dev)
         for p in range(parts):
-            tr.render_tiled_dev(sc, g, pc, W, H, abi.trt_tiling(group, parts, p, 0), direct.data_ptr(), stream=s)
+            tr.render_tiled_dev(sc, g, pc, W, H, abi.trt_tiling(group, parts, p, 0), direct.data_ptr(), camera=cam, stream=s)
         torch.cuda.synchronize()
     finally:
         tr.set_render_variant("listed")
