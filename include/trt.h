@@ -174,7 +174,10 @@ int trt_trace_dev(trt_ctx* ctx, const trt_rays* in_dev, const trt_scene* scene,
  * first_hit_out: optional SoA record of the depth-0 hit per pixel, row-major y*W+x. */
 int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
                uint32_t W, uint32_t H, int camera, float* rgba_out, trt_hits* first_hit_out);
-/* Rows [row_begin,row_end) only; outputs are indexed relative to the FULL image, so a
+/* The *_dev entry points allocate nothing and synchronise nothing once the ctx's scratch has been
+ * sized by a first call, so a frame loop on them can be captured into a hipGraph and replayed.
+ *
+ * Rows [row_begin,row_end) only; outputs are indexed relative to the FULL image, so a
  * rank that owns a row band passes pointers to the full-frame buffers (or to buffers
  * offset by -row_begin*W elements).  rendered_dev is optional (BEF RenderedData, x*H+y). */
 int trt_render_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,

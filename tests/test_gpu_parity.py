@@ -493,6 +493,53 @@ def test_random_scenes(tr, oracle, seed):
             tr.set_render_variant("listed")
 
 
+def test_render_is_graph_capturable(tr):
+    """trt_render_dev makes no allocation and no synchronisation once its buffers exist, so a frame
+    loop can be captured into a hipGraph (small frames are launch-bound: two launches per frame)
+    and replayed: the replays reproduce the eager frames bit for bit, and — with ONE frame per
+    graph, which never meets the frame that would have zeroed its counter set — the double-buffered
+    list counters do not accumulate from replay to replay (the query counts stay those of ONE frame)."""
+    import torch
+    dev = torch.device("cuda:0")
+    W = H = 256
+    sc, g = camera.single_torus_scene(), camera.baseline_camera(W, H)
+    pcs = [camera.baseline_push(d) for d in (1, 3, 5)]
+    eager = [torch.zeros(H, W, 4, device=dev) for _ in pcs]
+    cur = torch.cuda.current_stream()
+    tr.enable_stats(True)
+    try:
+        for img, pc in zip(eager, pcs):           # also sizes the ctx's tile lists before the capture
+            tr.render_dev(sc, g, pc, W, H, img.data_ptr(), stream=cur.cuda_stream)
+        want_stats = tr.stats()                    # of the last eager frame
+        replayed = [torch.zeros(H, W, 4, device=dev) for _ in pcs]
+        graphs = []
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for img, pc in zip(replayed, pcs):     # ONE frame per graph: the hardest case for the counters
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    tr.render_dev(sc, g, pc, W, H, img.data_ptr(), stream=side.cuda_stream)
+                graphs.append(gr)
+        cur.wait_stream(side)
+        for _ in range(12):
+            for img, gr in zip(replayed, graphs):
+                img.zero_()
+                gr.replay()
+        torch.cuda.synchronize()
+        got_stats = tr.stats()
+    finally:
+        tr.enable_stats(False)
+    for a, b in zip(eager, replayed):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert got_stats == want_stats and got_stats["primary_tests"] == W * H
+    # an eager frame after the replays sees clean counters too
+    again = torch.zeros(H, W, 4, device=dev)
+    tr.render_dev(sc, g, pcs[2], W, H, again.data_ptr(), stream=cur.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int32), eager[2].view(torch.int32))
+
+
 def test_post_pass_bit_exact(tr, oracle):
     """trt_post_dev (tonemap of post.frag) — float and UNORM8 outputs bit for bit equal to the
     oracle: the exp2/log2 polynomials use only correctly rounded operations."""

@@ -521,6 +521,18 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     if(a.n_local_rows && W) ctx->queue_parity ^= 1;  // an empty launch runs no kernel: keep the zeroed set
   }
   ctx->last_stream = st;
+  if(ctx->variant != kRenderStatic)
+  {
+    // The counter set of a frame is zeroed by the frame before it — in the order the HOST issued
+    // them.  A captured graph replays its frames without the host, so a graph with an odd number
+    // of frames would start its replays on the set its own last frame left dirty: while the
+    // stream is capturing, the frame zeroes its own set with a memset node.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if(hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
+      TRT_HIP(ctx, hipMemsetAsync(a.queue, 0, 32 * sizeof(unsigned int), st));
+    else
+      (void)hipGetLastError();
+  }
   TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
   if(ctx->variant != kRenderStatic && getenv("TRT_DEBUG_TILES"))
   {
