@@ -526,10 +526,10 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     // The counter set of a frame is zeroed by the frame before it — in the order the HOST issued
     // them.  A captured graph replays its frames without the host, so a graph with an odd number
     // of frames would start its replays on the set its own last frame left dirty: while the
-    // stream is capturing, the frame zeroes its own set with a memset node.
+    // stream is capturing, the frame zeroes its own set with a one-wave kernel node.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if(hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
-      TRT_HIP(ctx, hipMemsetAsync(a.queue, 0, 32 * sizeof(unsigned int), st));
+      TRT_HIP(ctx, launch_zero_counters(a.queue, st));   // a kernel node (memset nodes faulted on replay, ROCm 7.2)
     else
       (void)hipGetLastError();
   }

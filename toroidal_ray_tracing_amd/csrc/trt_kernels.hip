@@ -1188,6 +1188,16 @@ hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t str
   return hipGetLastError();
 }
 
+// Zeroes one set of tile-list counters (32 words) — used only while a stream is being captured
+// into a hipGraph, where the frame cannot rely on the host-ordered previous frame to do it.
+__global__ void zero_counters_kernel(unsigned int* q) { q[threadIdx.x] = 0u; }
+
+hipError_t launch_zero_counters(unsigned int* queue, hipStream_t stream)
+{
+  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(32), 0, stream, queue);
+  return hipGetLastError();
+}
+
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
                          hipStream_t stream)
 {

@@ -52,6 +52,7 @@ hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp
                         const float* clear, float point_size, unsigned long long* keys, float* rgba, int n_cus,
                         hipStream_t stream);
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
+hipError_t launch_zero_counters(unsigned int* queue, hipStream_t stream);
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
                          hipStream_t stream);
 
