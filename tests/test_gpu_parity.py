@@ -493,6 +493,33 @@ def test_random_scenes(tr, oracle, seed):
             tr.set_render_variant("listed")
 
 
+def test_frame_sequences_keep_no_state(oracle):
+    """One ctx, 40 frames in a row that change size, camera model, scene, kernel variant, solver and
+    depth at random: every frame must equal the oracle's — nothing (tile lists, their
+    double-buffered counters, the cached toroidal tables, grow-only scratch) may leak from one
+    frame into the next."""
+    from toroidal_ray_tracing_amd.tracer import Tracer
+    rng = np.random.default_rng(4242)
+    t = Tracer(0)
+    try:
+        for k in range(40):
+            sc, g, pc, W, H, cam = random_case(int(rng.integers(0, 24)))
+            W, H = int(rng.integers(1, 26)) * 8 + int(rng.integers(0, 8)), int(rng.integers(1, 20)) * 8 + int(rng.integers(0, 8))
+            g = camera.globals_for(tuple(rng.normal(size=3) * 3.0), tuple(rng.uniform(-1, 1, 3) + (np.array([6.0, 0, 0]) if cam else 0)), W, H,
+                                   fov_deg=float(rng.uniform(25, 100)))
+            variant = ["listed", "persistent", "static"][int(rng.integers(0, 3))]
+            solver = [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64][int(rng.integers(0, 2))]
+            t.set_render_variant(variant)
+            t.set_solver(solver)
+            t.enable_stats(bool(rng.integers(0, 2)))
+            rgba, hits = t.render(sc, g, pc, W, H, cam)
+            wr, wh, _, _ = oracle.render(sc, g, pc, W, H, cam, precision=solver, nthreads=8)
+            assert_hits_equal(hits, wh, f"frame {k} ({variant}, {W}x{H}, cam {cam})")
+            np.testing.assert_allclose(rgba, wr, rtol=COLOR_RTOL, atol=COLOR_ATOL)
+    finally:
+        t.close()
+
+
 def test_render_is_graph_capturable(tr):
     """trt_render_dev makes no allocation and no synchronisation once its buffers exist, so a frame
     loop can be captured into a hipGraph (small frames are launch-bound: two launches per frame)
