@@ -242,7 +242,7 @@ int trt_splat_dev(trt_ctx* ctx, const trt_point* points_dev, uint64_t n_points, 
 
 /* Counters of the last render or trace call made with counting enabled. */
 int trt_enable_stats(trt_ctx* ctx, int on);
-int trt_get_stats(trt_ctx* ctx, trt_stats* out); /* synchronises the ctx's last stream   */
+int trt_get_stats(trt_ctx* ctx, trt_stats* out); /* waits for the last counted launch (a graph replay: synchronise it yourself) */
 
 /* Name of the kernel variant used by trt_render* ("persistent" | "static"). */
 int         trt_set_render_variant(trt_ctx* ctx, const char* name);

@@ -37,7 +37,10 @@ struct trt_ctx {
   RenderVariant variant   = kRenderListed;
   bool          stats_on  = false;
   std::string   err;
-  hipStream_t   last_stream = nullptr;
+  // Events instead of remembered stream handles (the caller may destroy a stream between calls):
+  hipEvent_t    ev_toro  = nullptr;   // the last upload of the toroidal tables has read its host staging
+  hipEvent_t    ev_stats = nullptr;   // the last counted launch is done
+  bool          ev_toro_set = false, ev_stats_set = false;
 
   unsigned long long* d_stats = nullptr;  // [4]
   unsigned int*       d_queue = nullptr;  // tile-list counters, two sets of 32 words (double-buffered)
@@ -210,8 +213,8 @@ int build_toro(trt_ctx* ctx, const trt_globals& g, const trt_push& pc, uint32_t 
       TRT_HIP(ctx, hipHostMalloc((void**)&ctx->h_toro, n * sizeof(float), hipHostMallocDefault));
       ctx->h_toro_cap = n;
     }
-    else if(ctx->last_stream || key.valid)
-      TRT_HIP(ctx, hipStreamSynchronize(ctx->last_stream));  // an earlier upload may be reading it
+    else if(ctx->ev_toro_set)
+      TRT_HIP(ctx, hipEventSynchronize(ctx->ev_toro));  // an earlier upload may still be reading it
     float* ca = ctx->h_toro, *sa = ca + W, *cb = sa + W, *sb = cb + H;
     const float d_alfa = 360.0f / (float)W, d_beta = 360.0f / (float)H;      // :25-26
     for(uint32_t x = 0; x < W; ++x)
@@ -228,6 +231,8 @@ int build_toro(trt_ctx* ctx, const trt_globals& g, const trt_push& pc, uint32_t 
     }
     TRT_HIP(ctx, hipMemcpyAsync(ctx->d_toro.p, ctx->h_toro, n * sizeof(float), hipMemcpyHostToDevice,
                                 stream));
+    TRT_HIP(ctx, hipEventRecord(ctx->ev_toro, stream));
+    ctx->ev_toro_set = true;
     key.W = W; key.H = H; key.omega = omega; key.theta = theta; key.valid = true;
   }
   out.eye[0] = eye[0]; out.eye[1] = eye[1]; out.eye[2] = eye[2];
@@ -271,7 +276,9 @@ extern "C" int trt_create(int device, trt_ctx** out)
      || (e = hipMalloc((void**)&ctx->d_stats, 4 * sizeof(unsigned long long))) != hipSuccess
      || (e = hipMalloc((void**)&ctx->d_queue, 64 * sizeof(unsigned int))) != hipSuccess
      || (e = hipMemset(ctx->d_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess
-     || (e = hipMemset(ctx->d_queue, 0, 64 * sizeof(unsigned int))) != hipSuccess)
+     || (e = hipMemset(ctx->d_queue, 0, 64 * sizeof(unsigned int))) != hipSuccess
+     || (e = hipEventCreateWithFlags(&ctx->ev_toro, hipEventDisableTiming)) != hipSuccess
+     || (e = hipEventCreateWithFlags(&ctx->ev_stats, hipEventDisableTiming)) != hipSuccess)
   {
     fail(nullptr, TRT_E_HIP, "trt_create: %s", hipGetErrorString(e));
     trt_destroy(ctx);
@@ -286,6 +293,8 @@ extern "C" void trt_destroy(trt_ctx* ctx)
 {
   if(!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if(ctx->ev_toro) (void)hipEventDestroy(ctx->ev_toro);
+  if(ctx->ev_stats) (void)hipEventDestroy(ctx->ev_stats);
   if(ctx->d_stats) (void)hipFree(ctx->d_stats);
   if(ctx->d_queue) (void)hipFree(ctx->d_queue);
   if(ctx->h_toro) (void)hipHostFree(ctx->h_toro);
@@ -335,7 +344,7 @@ extern "C" int trt_get_stats(trt_ctx* ctx, trt_stats* out)
 {
   if(!ctx || !out) return TRT_E_INVALID;
   TRT_HIP(ctx, hipSetDevice(ctx->device));
-  TRT_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+  if(ctx->ev_stats_set) TRT_HIP(ctx, hipEventSynchronize(ctx->ev_stats));
   unsigned long long h[4];
   TRT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
   out->primary_tests = h[0];
@@ -371,8 +380,12 @@ extern "C" int trt_trace_dev(trt_ctx* ctx, const trt_rays* in, const trt_scene* 
     a.stats           = ctx->d_stats;
     ctx->stats_pixels = in->n;
   }
-  ctx->last_stream = st;
   TRT_HIP(ctx, launch_trace(S, a, st));
+  if(ctx->stats_on)
+  {
+    TRT_HIP(ctx, hipEventRecord(ctx->ev_stats, st));
+    ctx->ev_stats_set = true;
+  }
   return TRT_OK;
 }
 
@@ -520,7 +533,6 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     a.queue_next = ctx->d_queue + 32 * (ctx->queue_parity ^ 1);
     if(a.n_local_rows && W) ctx->queue_parity ^= 1;  // an empty launch runs no kernel: keep the zeroed set
   }
-  ctx->last_stream = st;
   if(ctx->variant != kRenderStatic)
   {
     // The counter set of a frame is zeroed by the frame before it — in the order the HOST issued
@@ -534,6 +546,16 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
       (void)hipGetLastError();
   }
   TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
+  if(ctx->stats_on)
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if(hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusActive)
+    {
+      (void)hipGetLastError();
+      TRT_HIP(ctx, hipEventRecord(ctx->ev_stats, st));
+      ctx->ev_stats_set = true;
+    }
+  }
   if(ctx->variant != kRenderStatic && getenv("TRT_DEBUG_TILES"))
   {
     unsigned int q[2];
@@ -620,7 +642,6 @@ extern "C" int trt_post_dev(trt_ctx* ctx, const float* rgba_in, uint64_t n_pixel
   if(((uintptr_t)rgba_in | (uintptr_t)f32_out) & 15 || ((uintptr_t)unorm8_out & 3))
     return fail(ctx, TRT_E_INVALID, "trt_post: images must be 16-byte (float) / 4-byte (unorm8) aligned");
   TRT_HIP(ctx, hipSetDevice(ctx->device));
-  ctx->last_stream = (hipStream_t)stream;
   TRT_HIP(ctx, launch_post(rgba_in, n_pixels, f32_out, unorm8_out, ctx->n_cus, (hipStream_t)stream));
   return TRT_OK;
 }
@@ -641,7 +662,6 @@ extern "C" int trt_splat_dev(trt_ctx* ctx, const trt_point* points, uint64_t n_p
     return fail(ctx, TRT_E_INVALID, "trt_splat: point_size %g outside (0, 64]", (double)point_size);
   TRT_HIP(ctx, hipSetDevice(ctx->device));
   if(int rc = grow(ctx, ctx->d_keys, (size_t)W * H * sizeof(unsigned long long))) return rc;
-  ctx->last_stream = (hipStream_t)stream;
   TRT_HIP(ctx, launch_splat(points, n_points, viewProj, W, H, clearColor, point_size,
                             (unsigned long long*)ctx->d_keys.p, rgba, ctx->n_cus, (hipStream_t)stream));
   return TRT_OK;
