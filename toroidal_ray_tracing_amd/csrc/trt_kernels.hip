@@ -130,13 +130,30 @@ __device__ __forceinline__ void store_first_hit(const RenderArgs& a, size_t i_, 
   if(a.hits.id) st1(a.hits.id, i, id);
 }
 
-// wave-level sum of a 32-bit counter, then one atomic per wave
-__device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v)
+// Query counters of a block → the three global totals: wave sums by shuffles, block sums by LDS
+// atomics, then ONE global atomic per counter per block (65,536 waves adding to three words one
+// by one made the counted pass of the listed kernel 1.2 ms long).  Every thread of the block must
+// call it (it contains barriers); `stats` is kernel-uniform.
+__device__ __forceinline__ void block_add3(unsigned long long* stats, uint32_t v0, uint32_t v1, uint32_t v2)
 {
+  __shared__ unsigned int acc[3];
+  if(threadIdx.x < 3) acc[threadIdx.x] = 0u;
+  __syncthreads();
   for(int off = 32; off > 0; off >>= 1)
-    v += __shfl_down(v, off, 64);
-  if((threadIdx.x & 63) == 0 && v)
-    atomicAdd(dst, (unsigned long long)v);
+  {
+    v0 += __shfl_down(v0, off, 64);
+    v1 += __shfl_down(v1, off, 64);
+    v2 += __shfl_down(v2, off, 64);
+  }
+  if((threadIdx.x & 63) == 0)
+  {
+    if(v0) atomicAdd(&acc[0], v0);
+    if(v1) atomicAdd(&acc[1], v1);
+    if(v2) atomicAdd(&acc[2], v2);
+  }
+  __syncthreads();
+  if(threadIdx.x < 3 && acc[threadIdx.x])
+    atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
 // Retire every outstanding load of this wave, then hide the given registers from hipcc's
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
     if(a.hits.id) a.hits.id[i] = id;
   }
   if(a.stats)
-    wave_add(&a.stats[0], tests);
+    block_add3(a.stats, tests, 0u, 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -291,9 +308,7 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
     trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
   if(a.stats)
   {
-    wave_add(&a.stats[0], n_primary);
-    wave_add(&a.stats[1], n_bounce);
-    wave_add(&a.stats[2], n_shadow);
+    block_add3(a.stats, n_primary, n_bounce, n_shadow);
   }
 }
 
@@ -925,9 +940,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 
   if(a.stats)
   {
-    wave_add(&a.stats[0], n_primary);
-    wave_add(&a.stats[1], n_bounce);
-    wave_add(&a.stats[2], n_shadow);
+    block_add3(a.stats, n_primary, n_bounce, n_shadow);
   }
 }
 
@@ -1019,9 +1032,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES
     }
   if(STATS && a.stats)   // STATS = false: the three counters are dead code (3 VGPRs and their increments)
   {
-    wave_add(&a.stats[0], n_primary);
-    wave_add(&a.stats[1], n_bounce);
-    wave_add(&a.stats[2], n_shadow);
+    block_add3(a.stats, n_primary, n_bounce, n_shadow);
   }
 }
 
