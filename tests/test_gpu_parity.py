@@ -493,6 +493,36 @@ def test_random_scenes(tr, oracle, seed):
             tr.set_render_variant("listed")
 
 
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
+def test_unaligned_hit_streams(tr, variant):
+    """First-hit streams that are only 4-byte aligned (the clear path then may not use its
+    dwordx4 stores) and a subset of the streams: same bits as the aligned render."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H = 256, 96
+    sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(3)
+    s = torch.cuda.current_stream().cuda_stream
+    names = ("t", "pz", "ny", "id")
+    tr.set_render_variant(variant)
+    try:
+        ref = {k: torch.zeros(W * H, device=dev, dtype=torch.int32 if k == "id" else torch.float32) for k in names}
+        img0 = torch.zeros(H, W, 4, device=dev)
+        tr.render_dev(sc, g, pc, W, H, img0.data_ptr(), hit_ptrs={k: v.data_ptr() for k, v in ref.items()}, stream=s)
+        big = {k: torch.zeros(W * H + 3, device=dev, dtype=ref[k].dtype) for k in names}
+        off = {"t": 1, "pz": 2, "ny": 3, "id": 1}
+        img1 = torch.zeros(H, W, 4, device=dev)
+        tr.render_dev(sc, g, pc, W, H, img1.data_ptr(),
+                      hit_ptrs={k: big[k][off[k]:].data_ptr() for k in names}, stream=s)
+        torch.cuda.synchronize()
+    finally:
+        tr.set_render_variant("listed")
+    assert torch.equal(img0.view(torch.int32), img1.view(torch.int32))
+    for k in names:
+        got = big[k][off[k]:off[k] + W * H]
+        assert torch.equal(got.view(torch.int32), ref[k].view(torch.int32)), k
+        assert big[k][:off[k]].abs().sum().item() == 0 and big[k][off[k] + W * H:].abs().sum().item() == 0   # nothing written outside
+
+
 def test_frame_sequences_keep_no_state(oracle):
     """One ctx, 40 frames in a row that change size, camera model, scene, kernel variant, solver and
     depth at random: every frame must equal the oracle's — nothing (tile lists, their
