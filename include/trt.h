@@ -170,7 +170,7 @@ int trt_trace_dev(trt_ctx* ctx, const trt_rays* in_dev, const trt_scene* scene,
                   float tmin, float tmax, trt_hits* out_dev, void* stream);
 
 /* ---- render: the faithful equivalent of HelloVulkan::raytrace ---------------------- */
-/* rgba_out: W*H*4 floats, row-major, image[y][x] = (hitValue, 1)  (rgen:87).
+/* rgba_out: W*H*4 floats, row-major, image[y][x] = (hitValue, 1)  (rgen:87); 16-byte aligned.
  * first_hit_out: optional SoA record of the depth-0 hit per pixel, row-major y*W+x. */
 int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
                uint32_t W, uint32_t H, int camera, float* rgba_out, trt_hits* first_hit_out);

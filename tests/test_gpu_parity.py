@@ -120,6 +120,12 @@ def test_error_codes(tr):
     assert e.value.code == abi.TRT_E_INVALID
     with pytest.raises(TrtError):
         tr.set_render_variant("nope")
+    import torch
+    img = torch.zeros(8 * 8 * 4 + 4, device="cuda:0")
+    with pytest.raises(TrtError) as e:   # float4 stores need a 16-byte aligned image
+        tr.render_dev(camera.single_torus_scene(), camera.baseline_camera(8, 8), camera.baseline_push(1), 8, 8,
+                      img[1:].data_ptr())
+    assert e.value.code == abi.TRT_E_INVALID
 
 
 RENDERS = {

@@ -455,6 +455,15 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     return fail(ctx, TRT_E_INVALID, "trt_render: W*H=%llu exceeds 2^31-1 pixels", (unsigned long long)W * H);
   if(camera != TRT_CAMERA_PINHOLE && camera != TRT_CAMERA_TOROIDAL)
     return fail(ctx, TRT_E_INVALID, "trt_render: unknown camera %d", camera);
+  if(((uintptr_t)rgba | (uintptr_t)rendered) & 15)
+    return fail(ctx, TRT_E_INVALID, "trt_render: the rgba image and the RenderedData buffer must be 16-byte aligned (they are written as float4)");
+  if(first_hit)
+  {
+    const void* hp[8] = {first_hit->t, first_hit->px, first_hit->py, first_hit->pz, first_hit->nx, first_hit->ny, first_hit->nz, first_hit->id};
+    for(const void* q : hp)
+      if((uintptr_t)q & 3)
+        return fail(ctx, TRT_E_INVALID, "trt_render: first-hit streams must be 4-byte aligned");
+  }
   if(tiling && (tiling->group_rows == 0 || tiling->n_parts == 0 || tiling->part >= tiling->n_parts))
     return fail(ctx, TRT_E_INVALID, "trt_render_tiled: bad tiling group_rows=%u n_parts=%u part=%u",
                 tiling->group_rows, tiling->n_parts, tiling->part);
