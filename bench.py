@@ -5,27 +5,40 @@ Workload (BASELINE.json `metric`: "ray-torus intersections/sec at 4096² × 4 bo
 BASELINE config 3 — single torus (R=1.0, r=0.25, mirror material), 4096×4096 primary rays,
 maxDepth 5 (= 1 primary + 4 reflection bounces, REFL/shaders/raytrace.rgen:79), FP32, pinhole
 camera at (0,1.5,-4) looking at the origin, point light (10,15,8) I=100, clear colour 1
-(SURVEY.md §8d).  One *step* = one full frame through the hot path (`trt_render_dev`):
-ray generation, closest-hit solve, Phong + shadow query, reflection bounces, and the
-rgba32f framebuffer + first-hit record written to HBM.  Inputs (camera matrices, push
-constants, scene: < 2 KB) travel as kernel arguments; outputs stay resident in HBM.
+(SURVEY.md §8d).  One *frame* = one pass of the hot path (`trt_render_dev`): ray generation,
+closest-hit solve, Phong + shadow query, reflection bounces, and the rgba32f framebuffer +
+first-hit record written to HBM.  Inputs (camera matrices, push constants, scene: < 2 KB) travel
+as kernel arguments; outputs stay resident in HBM.
 
-`value` = primary ray–torus intersection tests per second over the whole job (pixels ×
-tori × frames ÷ wall time, max over ranks); the bounce and shadow tests executed on top are
-reported in `config.tests_per_frame` and `total_tests_per_s` but never added to `value`.
+One *step* = one batch of `--frames-per-step` back-to-back frames (default 64 — the reference's
+frame loop renders 60 frames per rho value, BEF/main.cpp:337-341).  A single 0.15-ms frame per
+step would put the whole timed region of `--steps 20` inside the chip's clock ramp
+and below the resolution of any utilisation sampler; `ms_per_frame` is reported next to
+`ms_per_step`, and every per-launch figure (`roofline`) is per FRAME.
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): the SAME
-4096² frame is tiled across ranks in interleaved groups of rows (load balance: the torus
-sits in the middle rows) and the rgba32f framebuffer is all-gathered over RCCL/xGMI inside
-the timed step, as BASELINE.json north_star prescribes → "scaling": "strong".
+`value` = primary ray–torus intersection tests per second over the whole job (pixels × tori ×
+frames ÷ wall time, max over ranks); the bounce and shadow tests executed on top are reported in
+`config.tests_per_frame` and `total_tests_per_s` but never added to `value`.  85 % of the
+baseline frame's pixels lie in tiles the classification proves empty (their miss records are
+constant fills): `solved_tests_per_s` counts only the tests that pass the bounding-volume culls
+and build + walk a quartic, `traced_tests_per_s` the tests a lane executed at all.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--variant persistent|static]
-                       [--no-cpu-baseline] [--size 4096] [--depth 5]
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (a parent process that makes no GPU
+call runs `torch.distributed.run` and relays rank 0's JSON line); launched BY torch.distributed.run
+(RANK/WORLD_SIZE in the environment) it is one of the ranks.  The SAME 4096² frame is tiled across
+the ranks in interleaved groups of rows and the rgba32f framebuffer is all-gathered over RCCL/xGMI
+inside the timed step, as BASELINE.json north_star prescribes → "scaling": "strong".
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-step F]
+                       [--variant listed|persistent|static] [--gather fp32|rgba8|none]
+                       [--no-cpu-baseline] [--no-secondary] [--size 4096] [--depth 5]
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,32 +46,93 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
+FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 vector (spec), an FMA = 2 FLOP
+FP64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector (spec sheet; the guide's table lists FP32 only)
 BYTES_PER_PIXEL = 16 + 28       # rgba32f + first-hit record t,P,N
+BYTES_PER_RAY = 24 + 28         # trt_trace: ox..dz in, t,P,N out
+BYTES_PER_PIXEL_CAPTURE = 44 + 64   # + RenderedData AoS (BEF/shaders/host_device.h:101-107)
+
+# Algorithmic FLOPs of the intersection rows T1/T2, counted from
+# toroidal_ray_tracing_amd/csrc/trt_device.hpp with fma = 2, every other + - * / sqrt = 1:
+#   every traced test   TorusTest::setup up to the sphere cull: e = o - c (3), n (5), tc (1), q (6), m (5)      = 20
+#   every solved test   rest of setup: U (3), window (4), a b c (9), cylinder clip (4 + 2 + 6), slab clip (9),
+#                       kappa A4 P2 Q1 S0 (11), k6 w (4) = 52;  finish(): P (6), rho (4), e g s gh (12), du t (5) = 27  = 79
+#   every evaluation    step(): f (7), f' (5), f/f' and u - f/f' (2)                                             = 14
+# Ray generation, shading and the normal are NOT counted (they add < 10 % on the baseline frame).
+FLOP_PER_TRACED, FLOP_PER_SOLVED, FLOP_PER_EVAL = 20, 79, 14
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=64, help="frames in one step (one batch)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--variant", default=None, help="render kernel variant (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (N = 1 only)")
     ap.add_argument("--hits", default="tpn", choices=["tpn", "none"], help="first-hit record streams to write")
     ap.add_argument("--gather", default="fp32", choices=["fp32", "rgba8", "none"],
                     help="N>1: what is all-gathered after each frame (default: the rgba32f framebuffer)")
+    ap.add_argument("--group-rows", type=int, default=0, help="N>1: rows per interleaved group (0 = 8 cycles per frame)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: CPU rehearsal of the launcher and the gather (needs --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no measurement: every rank fills its rows with a rank pattern, the gather runs, "
+                         "rank 0 prints a line with value null (tests/test_distributed.py)")
     ap.add_argument("--center", default="0,0,0", help="camera look-at point (diagnostics; default = BASELINE)")
     return ap.parse_args()
 
 
+# ----------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` → N ranks.  Nothing here touches the GPU (a process that
+# has initialised HIP must not exec / the children own the devices).
+# ----------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(a):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for ln in p.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"n_gpus"' in t:
+            line = t
+        else:
+            sys.stderr.write(ln)   # anything else the ranks print is not the result line
+    rc = p.wait()
+    if rc != 0:
+        raise SystemExit(f"bench.py: the {a.gpus}-rank job failed (torch.distributed.run exit code {rc}); no result line")
+    if line is None:
+        raise SystemExit("bench.py: the ranks exited without a result line")
+    got = json.loads(line).get("n_gpus")
+    if got != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the job reports n_gpus={got}")
+    print(line, flush=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU baseline: the oracle timed on this host's cores (rank 0, N = 1 only)
+# ----------------------------------------------------------------------------------------------
 def cpu_baseline(sc, g, pc, W, H):
     """The oracle (a scalar C port — the reference has NO CPU path) timed on this host's cores:
-    whole frames of the same workload, OpenMP over 64-pixel blocks, until ~10-30 s of aggregate
-    CPU time have been spent (wall x threads), at most 8 frames."""
+    whole frames of the same workload, OpenMP over 64-pixel blocks, until ~15 s of aggregate CPU time
+    have been spent (wall x threads), at most 8 frames; then a bounded 1-thread sample (rows of the
+    same frame through the image centre, ~5-10 s), and BASELINE.md's configs 1 and 2 (256² and
+    2048², maxDepth 1) on one thread and on all cores."""
     import numpy as np
     from oracle import oracle
-    from toroidal_ray_tracing_amd import abi
+    from toroidal_ray_tracing_amd import abi, camera
     L = oracle.lib()
     cores = oracle.max_threads()
     rgba = np.zeros((H, W, 4), np.float32)
@@ -66,41 +140,235 @@ def cpu_baseline(sc, g, pc, W, H):
     for v in hits.values():
         v[...] = 0
     hs = abi.hits_struct({k: hits[k] for k in ("t", "px", "py", "pz", "nx", "ny", "nz")})
-    st = abi.trt_stats()
 
-    def run(r0, r1):
+    def run(gg, pp, w, h, r0, r1, threads):
+        st = abi.trt_stats()
         t0 = time.perf_counter()
-        rc = L.oracle_render(C.byref(g), C.byref(pc), C.byref(sc.c), W, H, r0, r1, 0, 0, cores,
+        rc = L.oracle_render(C.byref(gg), C.byref(pp), C.byref(sc.c), w, h, r0, r1, 0, 0, threads,
                              abi.ptr(rgba), C.byref(hs), None, C.byref(st))
         assert rc == 0
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, st
 
-    run(0, min(H, 64))  # warm up the thread pool and the page tables
+    run(g, pc, W, H, 0, min(H, 64), cores)  # warm up the thread pool and the page tables
     t, frames = 0.0, 0
     while frames < 8 and (frames < 2 or t * cores < 15.0):
-        t += run(0, H)
+        dt, st = run(g, pc, W, H, 0, H, cores)
+        t += dt
         frames += 1
     px = frames * W * H
-    return {"value": px * sc.n_tori / t, "unit": "primary ray-torus tests/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{frames} full {W}x{H} frames of the same workload ({t:.2f} s wall on {cores} "
-                      f"OpenMP threads = {t * cores:.0f} s of CPU time); build's C restatement of the "
-                      "reference's GLSL — the reference has no CPU path"}
+    out = {"value": px * sc.n_tori / t, "unit": "primary ray-torus tests/s", "cores": cores,
+           "kind": "port",
+           "sample": f"{frames} full {W}x{H} frames of the same workload ({t:.2f} s wall on {cores} "
+                     f"OpenMP threads = {t * cores:.0f} s of CPU time); build's C restatement of the "
+                     "reference's GLSL — the reference has no CPU path",
+           "solved_tests_per_s": frames * int(st.solved_tests) / t}
+    # one thread: a band of rows through the image centre (where the torus is: the expensive rows)
+    # and the same number of rows from the top (all misses), weighted to the whole frame
+    band = max(8, min(H // 2, 64))
+    t_mid, st_mid = run(g, pc, W, H, H // 2 - band // 2, H // 2 + band // 2, 1)
+    t_top, _ = run(g, pc, W, H, 0, band, 1)
+    out["one_thread"] = {"cores": 1, "sample": f"rows {H // 2 - band // 2}..{H // 2 + band // 2} (through the torus) and 0..{band} (all misses) "
+                                              f"of the same frame, {t_mid + t_top:.2f} s on one thread",
+                         "primary_tests_per_s_centre_rows": band * W * sc.n_tori / t_mid,
+                         "primary_tests_per_s_empty_rows": band * W * sc.n_tori / t_top,
+                         "solved_tests_per_s_centre_rows": int(st_mid.solved_tests) / t_mid}
+    # BASELINE.md "Configs": config 1 (256², maxDepth 1) and config 2 (2048², maxDepth 1), 1 thread and all cores
+    for name, w in (("config1_256", 256), ("config2_2048", 2048)):
+        gg, pp = camera.baseline_camera(w, w), camera.baseline_push(1)
+        run(gg, pp, w, w, 0, min(w, 64), cores)
+        ta, _ = run(gg, pp, w, w, 0, w, cores)
+        t1, _ = run(gg, pp, w, w, 0, w, 1)
+        out[name] = {"workload": f"single torus, {w}x{w} primary rays, maxDepth 1 (0 bounces), FP32",
+                     "all_cores_primary_tests_per_s": w * w * sc.n_tori / ta, "cores": cores,
+                     "one_thread_primary_tests_per_s": w * w * sc.n_tori / t1}
+    return out
 
 
-def main():
-    a = parse()
+# ----------------------------------------------------------------------------------------------
+# secondary configurations (N = 1): kernel time per launch, HIP events on the launch stream
+# ----------------------------------------------------------------------------------------------
+def secondary(tr, dev, stream):
+    import statistics
+    import torch
+    from toroidal_ray_tracing_amd import abi, camera
+
+    def timeit(fn, rounds=5, reps=10):
+        for _ in range(3):
+            fn()
+        out = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) / reps)
+        return statistics.median(out)
+
+    def flops(st):
+        return FLOP_PER_TRACED * st["traced_tests"] + FLOP_PER_SOLVED * st["solved_tests"] + FLOP_PER_EVAL * st["evaluations"]
+
+    def entry(name, ms, units, bytes_per_unit, st, dtype="f32", **kw):
+        gbs = bytes_per_unit * units / ms / 1e6
+        tf = flops(st) / ms / 1e9
+        peak = FP64_PEAK_TFLOPS if dtype == "f64" else FP32_PEAK_TFLOPS
+        e = {"name": name, "ms": ms, "units": units, "GB_per_s": gbs, "frac_hbm": gbs / HBM_PEAK_GBPS,
+             "TFLOP_per_s": tf, "frac_valu": tf / peak, "dtype": dtype,
+             "bound": "hbm" if gbs / HBM_PEAK_GBPS >= tf / peak else "valu",
+             "tests": {k: st[k] for k in ("primary_tests", "bounce_tests", "shadow_tests", "traced_tests", "solved_tests", "evaluations")}}
+        e.update(kw)
+        return e
+
+    res = []
+    s = stream.cuda_stream
+    # --- C2: trt_trace on 2048² rays: the frame's own primary rays (10 % hit) and rays all aimed at the torus
+    W = 2048
+    n = W * W
+    sc = camera.single_torus_scene()
+    g, pc1 = camera.baseline_camera(W, W), camera.baseline_push(1)
+    rend = torch.empty(n, 16, device=dev)
+    tr.render_dev(sc, g, pc1, W, W, 0, rendered_ptr=rend.data_ptr(), stream=s)
+    r = rend.view(W, W, 16).permute(1, 0, 2).reshape(-1, 16)   # x*H+y -> y*W+x
+    rays = [r[:, 8 + k].contiguous() for k in range(3)] + [r[:, 12 + k].contiguous() for k in range(3)]
+    del rend, r
+    out = {k: torch.empty(n, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
+    op = {k: v.data_ptr() for k, v in out.items()}
+
+    def trace_case(name, rays):
+        rp = [a.data_ptr() for a in rays]
+        tr.enable_stats(True)
+        tr.trace_dev(sc, rp, n, op, stream=s)
+        st = tr.stats()
+        tr.enable_stats(False)
+        ms = timeit(lambda: tr.trace_dev(sc, rp, n, op, stream=s))
+        hitf = torch.isfinite(out["t"]).float().mean().item()
+        res.append(entry(name, ms, n, BYTES_PER_RAY, st, kernel="trace_kernel", hit_fraction=hitf,
+                         tests_per_s=n * sc.n_tori / ms * 1e3))
+
+    trace_case("C2 trt_trace, 2048^2 camera rays, 0 bounces", rays)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    o = torch.rand(n, 3, device=dev, generator=gen) * 8 - 4
+    tgt = torch.randn(n, 3, device=dev, generator=gen)
+    tgt = tgt / tgt.norm(dim=1, keepdim=True) * (torch.rand(n, 1, device=dev, generator=gen) * 1.2)
+    d = tgt - o
+    d = d / d.norm(dim=1, keepdim=True)
+    trace_case("C2 trt_trace, 2048^2 random rays aimed at the torus", [o[:, k].contiguous() for k in range(3)] + [d[:, k].contiguous() for k in range(3)])
+    del rays, o, d, tgt
+
+    # --- renders at 4096²
+    W = 4096
+    n = W * W
+    rgba = torch.empty(W, W, 4, device=dev)
+    hits = {k: torch.empty(n, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
+    hp = {k: v.data_ptr() for k, v in hits.items()}
+
+    def render_case(name, sc, g, pc, cam=0, solver=abi.TRT_SOLVE_F32, variant="listed", Wr=W, Hr=W, rendered=None, bpp=BYTES_PER_PIXEL):
+        tr.set_solver(solver)
+        tr.set_render_variant(variant)
+        try:
+            kw = dict(camera=cam, hit_ptrs=hp, stream=s, rendered_ptr=rendered.data_ptr() if rendered is not None else 0)
+            tr.enable_stats(True)
+            tr.render_dev(sc, g, pc, Wr, Hr, rgba.data_ptr(), **kw)
+            st = tr.stats()
+            tr.enable_stats(False)
+            ms = timeit(lambda: tr.render_dev(sc, g, pc, Wr, Hr, rgba.data_ptr(), **kw))
+        finally:
+            tr.set_solver(abi.TRT_SOLVE_F32)
+            tr.set_render_variant("listed")
+        res.append(entry(name, ms, Wr * Hr, bpp, st, dtype="f64" if solver == abi.TRT_SOLVE_F64 else "f32",
+                         kernel=f"classify + render_{variant}_kernel", primary_tests_per_s=st["primary_tests"] / ms * 1e3,
+                         solved_tests_per_s=st["solved_tests"] / ms * 1e3))
+
+    render_case("C4 8 nested tori, 4096^2, maxDepth 5, FP64 solve", camera.nested_tori_scene(), camera.baseline_camera(W, W),
+                camera.baseline_push(5), solver=abi.TRT_SOLVE_F64)
+    render_case("C3 with the persistent-threads variant", camera.single_torus_scene(), camera.baseline_camera(W, W),
+                camera.baseline_push(5), variant="persistent")
+    # the namesake capture: toroidal camera inside an R=6 torus, 4096x2048, RenderedData exported
+    Wc, Hc = 4096, 2048
+    rend = torch.empty(Wc * Hc, 16, device=dev)
+    pcc = camera.baseline_push(5)
+    pcc.rho = 4.0
+    render_case("toroidal capture 4096x2048 with RenderedData (BEF)", camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC),
+                camera.toroidal_camera(Wc, Hc), pcc, cam=1, Wr=Wc, Hr=Hc, rendered=rend, bpp=BYTES_PER_PIXEL_CAPTURE)
+    return res
+
+
+# ----------------------------------------------------------------------------------------------
+# dry run (CPU rehearsal of launcher + gather; not a measurement)
+# ----------------------------------------------------------------------------------------------
+class _PatternTracer:
+    """Stands in for the Tracer in --dry-run: fills the rank's rows with (rank+1, row, x, 1)."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def tiling_rows(self, tiling, H):
+        from toroidal_ray_tracing_amd import distributed as trtd
+        return len(trtd.owned_rows(H, tiling.group_rows, tiling.n_parts, tiling.part))
+
+    def render_tiled_dev(self, scene, g, pc, W, H, tiling, rgba_ptr, camera=0, hit_ptrs=None, stream=0):
+        import numpy as np
+        from toroidal_ray_tracing_amd import distributed as trtd
+        rows = trtd.owned_rows(H, tiling.group_rows, tiling.n_parts, tiling.part)
+        buf = np.ctypeslib.as_array(C.cast(rgba_ptr, C.POINTER(C.c_float)), shape=(len(rows), W, 4))
+        buf[..., 0] = self.rank + 1
+        buf[..., 1] = np.asarray(rows, np.float32)[:, None]
+        buf[..., 2] = np.arange(W, dtype=np.float32)[None, :]
+        buf[..., 3] = 1.0
+
+    render_dev = None
+
+
+def dry_run(a, world, rank):
+    import torch
+    import torch.distributed as dist
+    from toroidal_ray_tracing_amd import distributed as trtd
+    if world > 1:
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
+    W = H = a.size
+
+    class _S:
+        cuda_stream = 0
+    frame = trtd.TiledFrame(_PatternTracer(rank), W, H, world, rank, torch.device("cpu"), group_rows=a.group_rows or None,
+                            gather=a.gather if a.gather != "rgba8" else "fp32")
+    ok = True
+    if world > 1:
+        for _ in range(3):
+            frame.render(None, None, None, 0, _S())
+        full = frame.finish()
+        G = frame.group_rows
+        rows = torch.arange(H)
+        ok = bool(torch.equal(full[:, 0, 0], ((rows // G) % world + 1).float()) and torch.equal(full[:, 0, 1], rows.float())
+                  and torch.equal(full[0, :, 2], torch.arange(W).float()))
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher + gather rehearsal, no measurement)", "value": None, "unit": None,
+                          "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True, "backend": a.backend,
+                          "gathered_frame_ok": ok, "tiling": frame.describe()}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("dry run: the gathered frame is wrong")
+
+
+# ----------------------------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------------------------
+def worker(a, world, rank, local):
     import torch
     import torch.distributed as dist
     from toroidal_ray_tracing_amd import abi, camera
     from toroidal_ray_tracing_amd.tracer import Tracer
     from toroidal_ray_tracing_amd import distributed as trtd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.backend != "nccl":
+        raise SystemExit("--backend gloo is the CPU rehearsal: add --dry-run (a measurement needs the GPUs and RCCL)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -108,6 +376,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W = H = a.size
+    F = max(1, a.frames_per_step)
     sc = camera.single_torus_scene()
     g = camera.baseline_camera(W, H) if a.center == "0,0,0" else camera.globals_for(
         (0.0, 1.5, -4.0), tuple(float(v) for v in a.center.split(",")), W, H)
@@ -118,47 +387,48 @@ def main():
     variant = tr.render_variant()
 
     frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else (),
-                            gather=a.gather)
+                            gather=a.gather, group_rows=a.group_rows or None)
     stream = torch.cuda.current_stream()
 
-    def step(ev=None):
+    def one_frame(ev=None):
         frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, stream, events=ev)
 
     # one counted pass (untimed): how many ray–torus tests one frame executes
     tr.enable_stats(True)
-    step()
+    one_frame()
     frame.finish()
     torch.cuda.synchronize()
     st = tr.stats()
     tr.enable_stats(False)
-    tests = torch.tensor([st["primary_tests"], st["bounce_tests"], st["shadow_tests"], st["pixels"]],
-                         dtype=torch.int64, device=dev)
+    keys = ("primary_tests", "bounce_tests", "shadow_tests", "pixels", "traced_tests", "solved_tests", "evaluations")
+    tests = torch.tensor([st[k] for k in keys], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(tests)
-    n_primary, n_bounce, n_shadow, n_pixels = (int(v) for v in tests.tolist())
-    if not os.environ.get("TRT_DEBUG_SKIP"):  # timing ablations skip part of the frame
-        assert n_pixels == W * H and n_primary == W * H * sc.n_tori
+    cnt = dict(zip(keys, (int(v) for v in tests.tolist())))
+    assert cnt["pixels"] == W * H and cnt["primary_tests"] == W * H * sc.n_tori
 
     for _ in range(a.warmup):
-        step()
+        for _ in range(F):
+            one_frame()
     frame.finish()
-    # HIP events on the launch stream.  N = 1: ONE pair around the K back-to-back frames (a pair
-    # per frame costs ≈10 µs of a 160-µs frame); N > 1: a pair around every frame's render
-    # launches, because the stream also carries the gather's wait and the de-interleave copy.
+    # HIP events on the launch stream (torch's current stream IS the stream handed to trt_render*_dev).
+    # N = 1: one pair around each step's F back-to-back frames; N > 1: a pair around every frame's render
+    # launches, because the stream also carries the waits on the gathers.
     per_frame = world > 1
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(a.steps if per_frame else 1)]
+           for _ in range(a.steps * (F if per_frame else 1))]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if not per_frame:
-        evs[0][0].record(stream)
     for k in range(a.steps):
-        step(evs[k] if per_frame else None)
-    if not per_frame:
-        evs[0][1].record(stream)
+        if not per_frame:
+            evs[k][0].record(stream)
+        for f in range(F):
+            one_frame(evs[k * F + f] if per_frame else None)
+        if not per_frame:
+            evs[k][1].record(stream)
     frame.finish()   # N > 1: the last frames' all-gathers are part of the K steps
     torch.cuda.synchronize()
     if world > 1:
@@ -169,38 +439,49 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    n_frames = a.steps * F
 
-    # dominant kernel: the render kernel, timed live with HIP events on the launch stream
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps
+    # dominant kernel(s) of one frame: classification + render kernel, timed live with HIP events
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / n_frames
     px_per_launch = frame.local_pixels
     achieved = BYTES_PER_PIXEL * px_per_launch / (kern_ms * 1e-3) / 1e9
+    flop_frame = (FLOP_PER_TRACED * st["traced_tests"] + FLOP_PER_SOLVED * st["solved_tests"] + FLOP_PER_EVAL * st["evaluations"])
+    tflops = flop_frame / (kern_ms * 1e-3) / 1e12
+    frac_hbm, frac_valu = achieved / HBM_PEAK_GBPS, tflops / FP32_PEAK_TFLOPS
 
-    # N > 1, diagnostics only (outside the timed region): the collective alone, so that the line shows
-    # what binds the step — the rank-local render (roofline.kernel_ms) or replicating the framebuffer
+    # N > 1, diagnostics only (outside the timed region): the collectives of one frame alone, so that the
+    # line shows what binds the step — the rank-local render (roofline.kernel_ms) or replicating the framebuffer
     gather_ms = None
     if world > 1 and frame.gather:
         try:
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             g0.record(stream)
+            span, G = frame.group_rows * world, frame.group_rows
             for _ in range(5):
-                dist.all_gather_into_tensor(frame.gathered[0], frame.sends[0])
+                for c in range(frame.cycles):
+                    dist.all_gather_into_tensor(frame.fulls[0][c * span:(c + 1) * span], frame.sends[0][c * G:(c + 1) * G])
             g1.record(stream)
             torch.cuda.synchronize()
             gather_ms = g0.elapsed_time(g1) / 5
         except Exception as e:  # never let a diagnostic break the benchmark line
             print(f"[bench] gather timing skipped: {e}", file=sys.stderr)
 
+    # HBM bytes per launch from the PMC passes of tools/make_profiles.sh (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE,
+    # separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The file records the
+    # kernel build it was measured on; a stale file yields null, not an old number.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(variant, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("size") == a.size and tj.get("depth") == a.depth:
+                traffic = tj.get(variant, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
     if rank == 0:
-        value = a.steps * n_primary / dt
+        value = n_frames * cnt["primary_tests"] / dt
         out = {
             "metric": "ray-torus intersections/sec at 4096^2 x 4 bounces (primary tests/s)",
             "value": value, "unit": "primary ray-torus tests/s", "n_gpus": world, "steps": a.steps,
@@ -208,27 +489,60 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config 3: single torus R=1 r=0.25 mirror, {W}x{H} primary rays, "
                                    f"maxDepth {a.depth} (= {a.depth - 1} reflection bounces), FP32, pinhole",
+                       "step": f"{F} back-to-back frames (one batch)", "frames_per_step": F,
                        "kernel_variant": variant, "n_tori": sc.n_tori,
-                       "tests_per_frame": {"primary": n_primary, "bounce": n_bounce, "shadow": n_shadow},
+                       "tests_per_frame": {"primary": cnt["primary_tests"], "bounce": cnt["bounce_tests"], "shadow": cnt["shadow_tests"],
+                                           "traced": cnt["traced_tests"], "solved": cnt["solved_tests"], "evaluations": cnt["evaluations"]},
                        "tiling": frame.describe()},
-            "total_tests_per_s": a.steps * (n_primary + n_bounce + n_shadow) / dt,
+            "ms_per_frame": dt / n_frames * 1e3,
+            "total_tests_per_s": n_frames * (cnt["primary_tests"] + cnt["bounce_tests"] + cnt["shadow_tests"]) / dt,
+            "traced_tests_per_s": n_frames * cnt["traced_tests"] / dt,
+            "solved_tests_per_s": n_frames * cnt["solved_tests"] / dt,
+            "flops": {"per_frame": flop_frame, "TFLOP_per_s": tflops, "peak_TFLOP_per_s": FP32_PEAK_TFLOPS, "frac": frac_valu,
+                      "model": f"{FLOP_PER_TRACED}/traced test + {FLOP_PER_SOLVED}/solved test + {FLOP_PER_EVAL}/evaluation of (f,f'); "
+                               "fma = 2; ray generation, normals and shading not counted"},
             "gather_ms": gather_ms,
             "target_primary_tests_per_s": 2.0e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "roofline": {"bound": "hbm" if frac_hbm >= frac_valu else "mfma", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": frac_hbm, "traffic": traffic,
+                         "frac_valu": frac_valu,
                          "kernel": (f"render_{variant}_kernel" if variant == "static"
                                     else f"tile_classify_kernel + render_{variant}_kernel (one frame)"),
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL, "pixels_per_launch": px_per_launch,
-                         "note": "mixture: ~80% of the pixels stream out HBM-bound, the rest is instruction-issue-bound root finding (DESIGN.md §5)"},
+                         "note": "what binds: the HBM fraction exceeds the FP32-VALU fraction by an order of magnitude, so the frame is priced "
+                                 "against HBM; it is a mixture — ~85 % of the pixels are constant fills at the store ceiling, the rest is "
+                                 "latency-bound root finding (DESIGN.md §5)"},
         }
+        if world == 1 and not a.no_secondary:
+            try:
+                out["secondary"] = secondary(tr, dev, stream)
+            except Exception as e:  # a secondary configuration must never cost the headline line
+                out["secondary_error"] = repr(e)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, g, pc, W, H)
+            cb = cpu_baseline(sc, g, pc, W, H)
+            out["cpu_baseline_1thread"] = cb.pop("one_thread")
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     tr.close()
+
+
+def main():
+    a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        return launch(a)          # plain `python bench.py --gpus N`: become the parent of N ranks
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong job size")
+    if a.dry_run:
+        return dry_run(a, world, rank)
+    worker(a, world, rank, local)
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define TRT_VERSION_MAJOR 0
-#define TRT_VERSION_MINOR 1
+#define TRT_VERSION_MINOR 2
 
 /* ---- status codes ------------------------------------------------------------------ */
 enum {
@@ -144,12 +144,21 @@ typedef struct trt_hits {
   int32_t* id;                     /* index of the torus hit                            */
 } trt_hits;
 
-/* Per-frame query counters (one "test" = one ray against one torus). */
+/* Per-frame query counters (one "test" = one ray against one torus).  primary_tests counts every
+ * pixel x torus, also for the pixels a tile classification answers without tracing (their miss
+ * record is written by a constant fill); traced_tests counts the tests a lane actually executed
+ * (primary on traced pixels + bounce + shadow), solved_tests those that passed the bounding-volume
+ * culls so that a quartic was built and walked (rows T1/T2 of SURVEY.md 8a), evaluations the
+ * (f, f') evaluations of the default solver's walk. */
 typedef struct trt_stats {
   uint64_t primary_tests;
   uint64_t bounce_tests;
   uint64_t shadow_tests;
   uint64_t pixels;
+  uint64_t traced_tests;
+  uint64_t solved_tests;
+  uint64_t evaluations;
+  uint64_t reserved;
 } trt_stats;
 
 typedef struct trt_ctx trt_ctx;
@@ -244,9 +253,16 @@ int trt_splat_dev(trt_ctx* ctx, const trt_point* points_dev, uint64_t n_points, 
 int trt_enable_stats(trt_ctx* ctx, int on);
 int trt_get_stats(trt_ctx* ctx, trt_stats* out); /* waits for the last counted launch (a graph replay: synchronise it yourself) */
 
-/* Name of the kernel variant used by trt_render* ("persistent" | "static"). */
+/* Name of the kernel variant used by trt_render* ("listed" (default) | "persistent" | "static"). */
 int         trt_set_render_variant(trt_ctx* ctx, const char* name);
 const char* trt_get_render_variant(const trt_ctx* ctx);
+
+/* Level of the tile classification of the listed / persistent variants: TRT_CLASSIFY_AUTO (default:
+ * per-tile for the toroidal camera and for a pinhole camera within two bounding radii of a torus,
+ * per-macro-tile otherwise), TRT_CLASSIFY_MACRO (32x8 pixels per test), TRT_CLASSIFY_TILE (8x8
+ * pixels per test + distance-function march).  Never changes an output bit, only the time. */
+enum { TRT_CLASSIFY_AUTO = -1, TRT_CLASSIFY_MACRO = 0, TRT_CLASSIFY_TILE = 1 };
+int trt_set_classification(trt_ctx* ctx, int level);
 
 #ifdef __cplusplus
 } /* extern "C" */

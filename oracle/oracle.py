@@ -87,7 +87,7 @@ def trace(scene, o, d, tmin=0.001, tmax=10000.0, precision=abi.TRT_SOLVE_F32, nt
     st = abi.trt_stats()
     _check(lib().oracle_trace(C.byref(rays), C.byref(scene.c), tmin, tmax, precision, nthreads,
                               C.byref(hs), C.byref(st)), "trace")
-    return out, {"primary_tests": st.primary_tests, "pixels": st.pixels}
+    return out, {k: int(getattr(st, k)) for k in abi.STAT_FIELDS}
 
 
 def render(scene, g, pc, W, H, camera=abi.TRT_CAMERA_PINHOLE, rows=None,
@@ -106,7 +106,7 @@ def render(scene, g, pc, W, H, camera=abi.TRT_CAMERA_PINHOLE, rows=None,
                                precision, nthreads, abi.ptr(rgba),
                                C.byref(hs) if hs is not None else None, abi.ptr(rendered),
                                C.byref(st)), "render")
-    stats = {k: getattr(st, k) for k in ("primary_tests", "bounce_tests", "shadow_tests", "pixels")}
+    stats = {k: int(getattr(st, k)) for k in abi.STAT_FIELDS}
     return rgba, hits, rendered, stats
 
 

@@ -151,18 +151,27 @@ static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
   return TRT_OK;
 }
 
+/* Work counters of the calling thread (trt_stats.solved_tests / .evaluations): tests that passed
+ * the bounding-volume culls of T1, and the polynomial evaluations of this file's formulation of
+ * the walk (the GPU's state machine visits the same points in a different bookkeeping; only
+ * solved_tests is comparable across the two). */
+static _Thread_local uint64_t tl_solved, tl_evals;
+
 /* One ray against one torus, in the scene's solver precision; result rounded to FP32. */
 static inline int torus_hit(const scene_t* S, int i, v3 o, v3 d, float dd, float inv_dd,
                             float tmin, float tmax, float* t, uint64_t* tests)
 {
   ++*tests;
+  int ne = 0, hit;
   if(S->f64)
   {
     const double o64[3] = {o.x, o.y, o.z}, d64[3] = {d.x, d.y, d.z};
     const double dd64   = fma(d64[2], d64[2], fma(d64[1], d64[1], d64[0] * d64[0]));
     double       t64;
-    if(!torus_first_hit_f64(o64, d64, dd64, 1.0 / dd64, (double)tmin, (double)tmax, &S->k64[i],
-                            S->dk, &t64, NULL))
+    hit = torus_first_hit_f64(o64, d64, dd64, 1.0 / dd64, (double)tmin, (double)tmax, &S->k64[i],
+                              S->dk, &t64, &ne);
+    if(ne) { ++tl_solved; tl_evals += (uint64_t)ne; }
+    if(!hit)
       return 0;
     const float tf = (float)t64;
     if(!(tf > tmin && tf < tmax)) /* rounding to FP32 may land on the open bounds */
@@ -171,7 +180,9 @@ static inline int torus_hit(const scene_t* S, int i, v3 o, v3 d, float dd, float
     return 1;
   }
   const float o32[3] = {o.x, o.y, o.z}, d32[3] = {d.x, d.y, d.z};
-  return torus_first_hit_f32(o32, d32, dd, inv_dd, tmin, tmax, &S->k32[i], S->dk, t, NULL);
+  hit = torus_first_hit_f32(o32, d32, dd, inv_dd, tmin, tmax, &S->k32[i], S->dk, t, &ne);
+  if(ne) { ++tl_solved; tl_evals += (uint64_t)ne; }
+  return hit;
 }
 
 /* Closest hit over all tori (role of traceRayEXT + BVH, REFL/shaders/raytrace.rgen:64-75):
@@ -448,19 +459,20 @@ int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* sce
   if(rc) return rc;
   if(!g || !pc || !W || !H || row_end > H || row_begin > row_end) return TRT_E_INVALID;
   const toro_frame F = toroidal_frame(g, pc);
-  uint64_t np = 0, nb = 0, ns = 0;
+  uint64_t np = 0, nb = 0, ns = 0, nsol = 0, nev = 0;
   (void)nthreads;
   /* work items: blocks of 64 pixels of a row (fine enough to keep >100 threads busy on an 8-row band) */
   const int64_t bpr = ((int64_t)W + 63) / 64, nblk = bpr * (int64_t)(row_end - row_begin);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads > 0 ? nthreads : 1) \
-    reduction(+ : np, nb, ns)
+    reduction(+ : np, nb, ns, nsol, nev)
 #endif
   for(int64_t blk = 0; blk < nblk; ++blk)
   {
     const uint32_t y  = row_begin + (uint32_t)(blk / bpr);
     const uint32_t xb = (uint32_t)(blk % bpr) * 64, xe = xb + 64 < W ? xb + 64 : W;
-    trt_stats st = {0, 0, 0, 0};
+    trt_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
+    tl_solved = tl_evals = 0;
     for(uint32_t x = xb; x < xe; ++x)
     {
       pixel_out o;
@@ -499,6 +511,8 @@ int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* sce
     np += st.primary_tests;
     nb += st.bounce_tests;
     ns += st.shadow_tests;
+    nsol += tl_solved;
+    nev += tl_evals;
   }
   if(stats)
   {
@@ -506,6 +520,10 @@ int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* sce
     stats->bounce_tests  = nb;
     stats->shadow_tests  = ns;
     stats->pixels        = (uint64_t)(row_end - row_begin) * W;
+    stats->traced_tests  = np + nb + ns;   /* the oracle traces every pixel */
+    stats->solved_tests  = nsol;
+    stats->evaluations   = nev;
+    stats->reserved      = 0;
   }
   return TRT_OK;
 }
@@ -518,18 +536,21 @@ int oracle_trace(const trt_rays* in, const trt_scene* scene, float tmin, float t
   int     rc = scene_prepare(scene, precision, &S);
   if(rc) return rc;
   if(!in || !out) return TRT_E_INVALID;
-  uint64_t np = 0;
+  uint64_t np = 0, nsol = 0, nev = 0;
   (void)nthreads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : np)
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : np, nsol, nev)
 #endif
   for(int64_t i = 0; i < (int64_t)in->n; ++i)
   {
     const v3 o = {in->ox[i], in->oy[i], in->oz[i]}, d = {in->dx[i], in->dy[i], in->dz[i]};
     float    t;
     uint64_t tests = 0;
+    tl_solved = tl_evals = 0;
     const int id = closest_hit(&S, o, d, tmin, tmax, &t, &tests);
     np += tests;
+    nsol += tl_solved;
+    nev += tl_evals;
     v3 P = {0.0f, 0.0f, 0.0f}, N = {0.0f, 0.0f, 0.0f};
     if(id >= 0)
     {
@@ -550,6 +571,10 @@ int oracle_trace(const trt_rays* in, const trt_scene* scene, float tmin, float t
     stats->primary_tests = np;
     stats->bounce_tests = stats->shadow_tests = 0;
     stats->pixels = in->n;
+    stats->traced_tests = np;
+    stats->solved_tests = nsol;
+    stats->evaluations  = nev;
+    stats->reserved     = 0;
   }
   return TRT_OK;
 }

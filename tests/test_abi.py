@@ -24,10 +24,24 @@ def test_library_exports_every_declared_symbol():
     L = lib.load()
     for name in _declared_functions():
         assert hasattr(L, name), name
-    assert L.trt_version() == 1
+    assert L.trt_version() == 2   # TRT_VERSION_MAJOR*1000 + TRT_VERSION_MINOR
+
+
+def test_release_library_reads_no_environment():
+    """Every TRT_* knob and the timing ablations are compiled out of libtrt.so (they exist in the
+    -DTRT_TUNING build libtrt_tuning.so that tools/ load): the release library imports no getenv."""
+    import subprocess
+    so = os.path.join(ROOT, "toroidal_ray_tracing_amd", "libtrt.so")
+    dyn = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in dyn
+    assert not hasattr(lib.load(), "trt_debug_reload_tuning")
+    tuning = os.path.join(ROOT, "toroidal_ray_tracing_amd", "libtrt_tuning.so")
+    if os.path.exists(tuning):
+        assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", tuning], capture_output=True, text=True, check=True).stdout
 
 
 def test_struct_layouts_match_header_comments():
+    assert C.sizeof(abi.trt_stats) == 64
     assert C.sizeof(abi.trt_globals) == 204   # 3 mat4 + vec3
     assert C.sizeof(abi.trt_push) == 44       # BEF PushConstantRay
     assert C.sizeof(abi.trt_material) == 80   # WaveFrontMaterial, scalar layout

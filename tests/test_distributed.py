@@ -1,5 +1,5 @@
-"""Multi-rank path on CPU (gloo, world_size 2): the row-group tiling, the all-gather and the
-de-interleave reproduce the single-rank frame.  The per-rank renders come from the CPU
+"""Multi-rank path on CPU (gloo, world_size 2): the row-group tiling and the in-place all-gathers
+reproduce the single-rank frame; `python bench.py --gpus 2` starts two ranks by itself.  The per-rank renders come from the CPU
 oracle here (there is no GPU in this container) through a stand-in tracer, so the REAL
 ``TiledFrame`` (pipelined all-gather, retire, finish) is what runs; on the GPU box the same
 class runs over RCCL (tests/test_gpu_parity.py::test_tiled_render_matches_full checks the
@@ -92,7 +92,7 @@ def _worker(rank, world, port, W, H, G, out):
         tr = _OracleTracer()
         sc, g = camera.single_torus_scene(), camera.baseline_camera(W, H)
         frame = trtd.TiledFrame(tr, W, H, world, rank, torch.device("cpu"), group_rows=G)
-        assert frame.local_rows == H // world and "pipelined" in frame.describe()
+        assert frame.local_rows == H // world and "pipelined" in frame.describe() and frame.cycles == H // (G * world)
         ok = True
         # three frames with different maxDepth through the two-deep pipeline; after finish() the
         # assembled frame is the LAST one, and after each step the frame from two steps ago is retired
@@ -127,3 +127,45 @@ def test_two_rank_gather_reproduces_frame():
         p.join(240)
     assert all(p.exitcode == 0 for p in procs)
     assert out.get(timeout=5) is True
+
+
+def _bench(args, env=None):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT,
+                          timeout=280, env=e)
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun around it): the parent spawns 2 ranks, relays rank 0's line, and
+    that line says n_gpus 2.  --backend gloo --dry-run is the CPU rehearsal: rank-coded rows instead of rendered
+    ones, the REAL TiledFrame gathers, every rank checks the assembled frame."""
+    import json
+    p = _bench(["--gpus", "2", "--backend", "gloo", "--dry-run", "--size", "64"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["gathered_frame_ok"] is True and out["value"] is None
+
+
+def test_bench_never_reports_the_wrong_job_size():
+    """--gpus 8 inside a 1-rank environment (or with fewer ranks than asked) exits non-zero without a result line."""
+    p = _bench(["--gpus", "8", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "{" not in p.stdout and "WORLD_SIZE=1" in p.stderr
+    # a measurement over gloo is refused as well (gloo is the rehearsal backend)
+    p = _bench(["--gpus", "1", "--backend", "gloo", "--no-cpu-baseline"])
+    assert p.returncode != 0 and "{" not in p.stdout
+
+
+def test_default_group_rows():
+    assert trtd.default_group_rows(4096, 8) == 64 and trtd.default_group_rows(4096, 2) == 256
+    assert trtd.default_group_rows(8192, 8) == 128 and trtd.default_group_rows(4096, 1) == 4096
+    assert trtd.default_group_rows(64, 2) == 8 and trtd.default_group_rows(48, 3) == 8
+    for H, N in [(4096, 8), (4096, 4), (4096, 2), (8192, 8), (64, 2), (48, 3)]:
+        G = trtd.default_group_rows(H, N)
+        assert H % (G * N) == 0

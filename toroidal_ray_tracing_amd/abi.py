@@ -16,6 +16,7 @@ TRT_OK, TRT_E_INVALID, TRT_E_NO_DEVICE, TRT_E_HIP, TRT_E_SCENE, TRT_E_NOMEM = 0,
 TRT_MAX_TORI = 8
 TRT_MAX_MATERIALS = 8
 TRT_CAMERA_PINHOLE, TRT_CAMERA_TOROIDAL = 0, 1
+TRT_CLASSIFY_AUTO, TRT_CLASSIFY_MACRO, TRT_CLASSIFY_TILE = -1, 0, 1
 TRT_SOLVE_F32, TRT_SOLVE_F64, TRT_SOLVE_DK_F32, TRT_SOLVE_DK_F64 = 0, 1, 2, 3
 TRT_SOLVE_FERRARI_F32, TRT_SOLVE_FERRARI_F64 = 4, 5
 
@@ -83,7 +84,12 @@ class trt_tiling(C.Structure):
 
 class trt_stats(C.Structure):
     _fields_ = [("primary_tests", C.c_uint64), ("bounce_tests", C.c_uint64),
-                ("shadow_tests", C.c_uint64), ("pixels", C.c_uint64)]
+                ("shadow_tests", C.c_uint64), ("pixels", C.c_uint64),
+                ("traced_tests", C.c_uint64), ("solved_tests", C.c_uint64),
+                ("evaluations", C.c_uint64), ("reserved", C.c_uint64)]
+
+
+STAT_FIELDS = ("primary_tests", "bounce_tests", "shadow_tests", "pixels", "traced_tests", "solved_tests", "evaluations")
 
 
 assert C.sizeof(trt_globals) == 204 and C.sizeof(trt_push) == 44

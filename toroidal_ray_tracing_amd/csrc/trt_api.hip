@@ -36,15 +36,17 @@ struct trt_ctx {
   int           precision = TRT_SOLVE_F32;
   RenderVariant variant   = kRenderListed;
   bool          stats_on  = false;
+  int           classify  = TRT_CLASSIFY_AUTO;
   std::string   err;
   // Events instead of remembered stream handles (the caller may destroy a stream between calls):
   hipEvent_t    ev_toro  = nullptr;   // the last upload of the toroidal tables has read its host staging
   hipEvent_t    ev_stats = nullptr;   // the last counted launch is done
   bool          ev_toro_set = false, ev_stats_set = false;
 
-  unsigned long long* d_stats = nullptr;  // [4]
-  unsigned int*       d_queue = nullptr;  // tile-list counters, two sets of 32 words (double-buffered)
-  int                 queue_parity = 0;
+  Tuning        tn;                       // launch-shape knobs: defaults, or the environment ONCE in a -DTRT_TUNING build
+  unsigned long long* d_stats = nullptr;  // [8]: trt_kernels.hip block_add_stats
+  unsigned int*       d_queue = nullptr;  // words 0..2: classification accumulators (zero between frames),
+                                          // words 32..33: the published list lengths (trt_kernels.hpp RenderArgs)
   uint64_t            stats_pixels = 0;
 
   // toroidal camera tables: device copy + pinned host staging + cache key
@@ -81,9 +83,26 @@ int fail(trt_ctx* ctx, int code, const char* fmt, ...)
                   hipGetErrorString(e_));                                                   \
   } while(0)
 
-int grow(trt_ctx* ctx, DevBuf& b, size_t bytes)
+bool capturing(hipStream_t st)
+{
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if(hipStreamIsCapturing(st, &cap) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return false;
+  }
+  return cap == hipStreamCaptureStatusActive;
+}
+
+// Grow-only scratch.  Growing frees the old block: a hipGraph captured earlier still holds the old
+// address (include/trt.h: size the ctx with an eager call first), and hipFree/hipMalloc are illegal
+// while `st` is being captured — then the call is refused instead.
+int grow(trt_ctx* ctx, DevBuf& b, size_t bytes, hipStream_t st = nullptr)
 {
   if(bytes <= b.cap) return TRT_OK;
+  if(capturing(st))
+    return fail(ctx, TRT_E_INVALID, "the ctx's scratch would have to grow (%zu -> %zu bytes) while the stream is being "
+                "captured into a hipGraph: make one eager call with the same sizes first", b.cap, bytes);
   if(b.p) TRT_HIP(ctx, hipFree(b.p));
   b.p = nullptr;
   b.cap = 0;
@@ -198,11 +217,15 @@ int build_toro(trt_ctx* ctx, const trt_globals& g, const trt_push& pc, uint32_t 
     if(ty < 0.0f) theta = 360.0f - theta;                                    // :50-52
   }
   const size_t n = 2 * ((size_t)W + H);
-  if(int rc = grow(ctx, ctx->d_toro, n * sizeof(float))) return rc;
+  if(int rc = grow(ctx, ctx->d_toro, n * sizeof(float), stream)) return rc;
   auto& key = ctx->toro_key;
   // bit-compare the angles so that a NaN frame (eye above centre) still caches
   const bool same = key.valid && key.W == W && key.H == H && !std::memcmp(&key.omega, &omega, 4)
                     && !std::memcmp(&key.theta, &theta, 4);
+  if(!same && capturing(stream))
+    return fail(ctx, TRT_E_INVALID, "toroidal camera: the trigonometry tables of this (W, H, centre, rho) frame are not on the "
+                "device yet and cannot be uploaded while the stream is being captured into a hipGraph (a replay would "
+                "copy whatever the staging buffer holds later): render the frame eagerly once before capturing it");
   if(!same)
   {
     if(ctx->h_toro_cap < n)
@@ -273,9 +296,9 @@ extern "C" int trt_create(int device, trt_ctx** out)
   ctx->device = device;
   hipDeviceProp_t prop;
   if((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess
-     || (e = hipMalloc((void**)&ctx->d_stats, 4 * sizeof(unsigned long long))) != hipSuccess
+     || (e = hipMalloc((void**)&ctx->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess
      || (e = hipMalloc((void**)&ctx->d_queue, 64 * sizeof(unsigned int))) != hipSuccess
-     || (e = hipMemset(ctx->d_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess
+     || (e = hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long))) != hipSuccess
      || (e = hipMemset(ctx->d_queue, 0, 64 * sizeof(unsigned int))) != hipSuccess
      || (e = hipEventCreateWithFlags(&ctx->ev_toro, hipEventDisableTiming)) != hipSuccess
      || (e = hipEventCreateWithFlags(&ctx->ev_stats, hipEventDisableTiming)) != hipSuccess)
@@ -285,6 +308,7 @@ extern "C" int trt_create(int device, trt_ctx** out)
     return TRT_E_HIP;
   }
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  ctx->tn    = tuning_from_env();
   *out = ctx;
   return TRT_OK;
 }
@@ -308,6 +332,16 @@ extern "C" void trt_destroy(trt_ctx* ctx)
   delete ctx;
 }
 
+#ifdef TRT_TUNING
+// tools/ only (libtrt_tuning.so): read the TRT_* knobs again, so that one process can time A against B
+extern "C" int trt_debug_reload_tuning(trt_ctx* ctx)
+{
+  if(!ctx) return TRT_E_INVALID;
+  ctx->tn = tuning_from_env();
+  return TRT_OK;
+}
+#endif
+
 extern "C" int trt_set_solver(trt_ctx* ctx, int precision)
 {
   if(!ctx) return TRT_E_INVALID;
@@ -324,6 +358,15 @@ extern "C" int trt_set_render_variant(trt_ctx* ctx, const char* name)
   else if(!std::strcmp(name, "persistent")) ctx->variant = kRenderPersistent;
   else if(!std::strcmp(name, "listed")) ctx->variant = kRenderListed;
   else return fail(ctx, TRT_E_INVALID, "trt_set_render_variant: unknown variant '%s'", name);
+  return TRT_OK;
+}
+
+extern "C" int trt_set_classification(trt_ctx* ctx, int level)
+{
+  if(!ctx) return TRT_E_INVALID;
+  if(level < TRT_CLASSIFY_AUTO || level > TRT_CLASSIFY_TILE)
+    return fail(ctx, TRT_E_INVALID, "trt_set_classification: %d is not one of the TRT_CLASSIFY_* constants", level);
+  ctx->classify = level;
   return TRT_OK;
 }
 
@@ -345,12 +388,16 @@ extern "C" int trt_get_stats(trt_ctx* ctx, trt_stats* out)
   if(!ctx || !out) return TRT_E_INVALID;
   TRT_HIP(ctx, hipSetDevice(ctx->device));
   if(ctx->ev_stats_set) TRT_HIP(ctx, hipEventSynchronize(ctx->ev_stats));
-  unsigned long long h[4];
+  unsigned long long h[8];
   TRT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
   out->primary_tests = h[0];
   out->bounce_tests  = h[1];
   out->shadow_tests  = h[2];
   out->pixels        = ctx->stats_pixels;
+  out->traced_tests  = h[4];
+  out->solved_tests  = h[5];
+  out->evaluations   = h[6];
+  out->reserved      = 0;
   return TRT_OK;
 }
 
@@ -376,11 +423,11 @@ extern "C" int trt_trace_dev(trt_ctx* ctx, const trt_rays* in, const trt_scene* 
   a.stats = nullptr;
   if(ctx->stats_on)
   {
-    TRT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), st));
+    TRT_HIP(ctx, launch_zero_words((unsigned int*)ctx->d_stats, 16, st));
     a.stats           = ctx->d_stats;
     ctx->stats_pixels = in->n;
   }
-  TRT_HIP(ctx, launch_trace(S, a, st));
+  TRT_HIP(ctx, launch_trace(S, a, ctx->tn, st));
   if(ctx->stats_on)
   {
     TRT_HIP(ctx, hipEventRecord(ctx->ev_stats, st));
@@ -489,12 +536,13 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
   a.rgba = rgba;
   if(first_hit) a.hits = *first_hit;
   a.rendered = rendered;
-  a.queue    = ctx->d_queue;
+  a.counters = ctx->d_queue;
+  a.counts   = ctx->d_queue + 32;
   if(camera == TRT_CAMERA_TOROIDAL)
     if(int rc = build_toro(ctx, *g, *pc, W, H, st, a.toro)) return rc;
   if(ctx->stats_on)
   {
-    TRT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), st));
+    TRT_HIP(ctx, launch_zero_words((unsigned int*)ctx->d_stats, 16, st));
     a.stats           = ctx->d_stats;
     ctx->stats_pixels = (uint64_t)a.n_local_rows * W;
   }
@@ -506,14 +554,15 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     if(W > 8u * 65535u || a.n_local_rows > 8u * 32767u)
       return fail(ctx, TRT_E_INVALID, "trt_render: the tile lists pack tile coordinates in 16 + 15 bits (W <= 524280, rows <= 262136)");
     const size_t n_tiles = (size_t)((W + 7) / 8) * ((a.n_local_rows + 7) / 8);
-    if(int rc = grow(ctx, ctx->d_tiles, 2 * n_tiles * sizeof(uint32_t))) return rc;
+    if(int rc = grow(ctx, ctx->d_tiles, 2 * n_tiles * sizeof(uint32_t), st)) return rc;
     a.tiles_live  = (uint32_t*)ctx->d_tiles.p;
     a.tiles_clear = a.tiles_live + n_tiles;
+    a.cap_live    = (uint32_t)n_tiles;
+    a.cap_clear   = (uint32_t)n_tiles;
     // tile culling needs tiles that are 8 contiguous image rows, and no per-pixel ray export
     a.tile_cull = (rendered == nullptr && (a.tile_parts <= 1 || a.tile_group % 8 == 0)) ? 1u : 0u;
-    a.min_batch = 24;
-    if(const char* e = getenv("TRT_MIN_BATCH")) a.min_batch = (uint32_t)atoi(e);
-    if(getenv("TRT_NO_TILE_CULL")) a.tile_cull = 0;
+    a.min_batch = ctx->tn.min_batch;
+    if(ctx->tn.no_tile_cull) a.tile_cull = 0;
     // The finer, per-tile classification costs 8 µs more at 4096² and pays when most macro tiles
     // touch a bounding volume: the toroidal camera looks in every direction from among the
     // geometry (inside a torus: 0.30 → 0.21 ms); for a pinhole camera outside the scene the
@@ -532,44 +581,25 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
         if(dx * dx + dy * dy + dz * dz < reach * reach) a.fine = 1u;
       }
     }
-    if(const char* e = getenv("TRT_FINE_CLASSIFY")) a.fine = (uint32_t)atoi(e);
-    if(const char* e = getenv("TRT_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(e);  // timing ablations only
+    if(ctx->classify != TRT_CLASSIFY_AUTO) a.fine = (uint32_t)ctx->classify;
+    if(ctx->tn.fine >= 0) a.fine = (uint32_t)ctx->tn.fine;
+    a.debug_skip = ctx->tn.debug_skip;   // always 0 in the release build
     uintptr_t bits = 0;
     const void* hp[8] = {a.hits.t, a.hits.px, a.hits.py, a.hits.pz, a.hits.nx, a.hits.ny, a.hits.nz, a.hits.id};
     for(const void* q : hp) bits |= (uintptr_t)q;
     a.vec4_ok = (W % 4 == 0 && (bits & 15) == 0) ? 1u : 0u;
-    a.queue      = ctx->d_queue + 32 * ctx->queue_parity;        // zeroed at create / by the previous frame
-    a.queue_next = ctx->d_queue + 32 * (ctx->queue_parity ^ 1);
-    if(a.n_local_rows && W) ctx->queue_parity ^= 1;  // an empty launch runs no kernel: keep the zeroed set
   }
-  if(ctx->variant != kRenderStatic)
+  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, ctx->tn, st));
+  if(ctx->stats_on && !capturing(st))
   {
-    // The counter set of a frame is zeroed by the frame before it — in the order the HOST issued
-    // them.  A captured graph replays its frames without the host, so a graph with an odd number
-    // of frames would start its replays on the set its own last frame left dirty: while the
-    // stream is capturing, the frame zeroes its own set with a one-wave kernel node.
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if(hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
-      TRT_HIP(ctx, launch_zero_counters(a.queue, st));   // a kernel node (memset nodes faulted on replay, ROCm 7.2)
-    else
-      (void)hipGetLastError();
+    TRT_HIP(ctx, hipEventRecord(ctx->ev_stats, st));
+    ctx->ev_stats_set = true;
   }
-  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, st));
-  if(ctx->stats_on)
-  {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if(hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusActive)
-    {
-      (void)hipGetLastError();
-      TRT_HIP(ctx, hipEventRecord(ctx->ev_stats, st));
-      ctx->ev_stats_set = true;
-    }
-  }
-  if(ctx->variant != kRenderStatic && getenv("TRT_DEBUG_TILES"))
+  if(ctx->variant != kRenderStatic && ctx->tn.debug_tiles)
   {
     unsigned int q[2];
     TRT_HIP(ctx, hipStreamSynchronize(st));
-    TRT_HIP(ctx, hipMemcpy(q, a.queue, sizeof q, hipMemcpyDeviceToHost));
+    TRT_HIP(ctx, hipMemcpy(q, a.counts, sizeof q, hipMemcpyDeviceToHost));
     fprintf(stderr, "[trt] tiles: live=%u clear=%u (cull=%u)\n", q[0], q[1], a.tile_cull);
   }
   return TRT_OK;
@@ -651,7 +681,7 @@ extern "C" int trt_post_dev(trt_ctx* ctx, const float* rgba_in, uint64_t n_pixel
   if(((uintptr_t)rgba_in | (uintptr_t)f32_out) & 15 || ((uintptr_t)unorm8_out & 3))
     return fail(ctx, TRT_E_INVALID, "trt_post: images must be 16-byte (float) / 4-byte (unorm8) aligned");
   TRT_HIP(ctx, hipSetDevice(ctx->device));
-  TRT_HIP(ctx, launch_post(rgba_in, n_pixels, f32_out, unorm8_out, ctx->n_cus, (hipStream_t)stream));
+  TRT_HIP(ctx, launch_post(rgba_in, n_pixels, f32_out, unorm8_out, ctx->n_cus, ctx->tn, (hipStream_t)stream));
   return TRT_OK;
 }
 
@@ -669,9 +699,11 @@ extern "C" int trt_splat_dev(trt_ctx* ctx, const trt_point* points, uint64_t n_p
     return fail(ctx, TRT_E_INVALID, "trt_splat: bad sizes W=%u H=%u n_points=%llu", W, H, (unsigned long long)n_points);
   if(!(point_size > 0.0f && point_size <= 64.0f))
     return fail(ctx, TRT_E_INVALID, "trt_splat: point_size %g outside (0, 64]", (double)point_size);
+  if(((uintptr_t)points | (uintptr_t)rgba) & 15)
+    return fail(ctx, TRT_E_INVALID, "trt_splat: the point buffer and the rgba image must be 16-byte aligned (float4 accesses)");
   TRT_HIP(ctx, hipSetDevice(ctx->device));
-  if(int rc = grow(ctx, ctx->d_keys, (size_t)W * H * sizeof(unsigned long long))) return rc;
+  if(int rc = grow(ctx, ctx->d_keys, (size_t)W * H * sizeof(unsigned long long), (hipStream_t)stream)) return rc;
   TRT_HIP(ctx, launch_splat(points, n_points, viewProj, W, H, clearColor, point_size,
-                            (unsigned long long*)ctx->d_keys.p, rgba, ctx->n_cus, (hipStream_t)stream));
+                            (unsigned long long*)ctx->d_keys.p, rgba, ctx->n_cus, ctx->tn, (hipStream_t)stream));
   return TRT_OK;
 }

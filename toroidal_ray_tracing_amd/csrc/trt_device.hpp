@@ -499,14 +499,25 @@ struct TorusTest {
   }
 };
 
+// Work counters of a lane (dead code in the kernels that do not store them): of the ray–torus
+// tests a lane executed, how many passed TorusTest::setup (a quartic was built and walked) and how
+// many evaluations of (f, f') the walks took — the numerator of the FLOP/s figure of bench.py.
+struct WorkCount {
+  uint32_t traced = 0;  // tests that ran TorusTest::setup (pixels of CLEAR tiles never do)
+  uint32_t solved = 0;  // … and passed it
+  uint32_t evals  = 0;  // evaluations of (f, f') by the default solver's walk
+};
+
 template <class Real, bool DK = false>
 __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
                                                 Real dz_, Real dd, Real inv_dd, Real tmin, Real tmax,
-                                                const TorusK<Real>& T, Real& t_out, int alt = 1)
+                                                const TorusK<Real>& T, Real& t_out, WorkCount& wc, int alt = 1)
 {
   TorusTest<Real> q;
+  ++wc.traced;
   if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))
     return false;
+  ++wc.solved;
   if(DK)
   {
     if(alt == 2) q.solve_ferrari(inv_dd, T.Rb2);   // wave-uniform: the scene's solver
@@ -518,6 +529,7 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
     bool run = true;
     while(run)
     {
+      ++wc.evals;
       if(__any(!q.iterating()))
         run = q.step();
       else
@@ -563,11 +575,11 @@ __device__ __forceinline__ bool round_t(double t, float tmin, float tmax, float&
 
 // One ray against torus i over the open interval (tmin, tmax); t rounded to FP32.
 template <class Real, bool DK = false>
-__device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t)
+__device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t, WorkCount& wc)
 {
   Real tt;
   if(!torus_first_hit<Real, DK>((Real)r.ox, (Real)r.oy, (Real)r.oz, (Real)r.dx, (Real)r.dy, (Real)r.dz, r.dd, r.inv_dd, (Real)r.tmin, (Real)tmax,
-                                torus_k<Real>(S, i), tt, S.dk))
+                                torus_k<Real>(S, i), tt, wc, S.dk))
     return false;
   return round_t(tt, tmin, tmax, t);
 }
@@ -579,7 +591,7 @@ __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Rea
 // Returns the torus index or -1; `tests` counts ray–torus tests.
 template <class Real, bool DK = false>
 __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
-                                           float& t_out, uint32_t& tests)
+                                           float& t_out, uint32_t& tests, WorkCount& wc)
 {
   RayK<Real> r;
   r.set(o, d, tmin, tmax);
@@ -590,7 +602,7 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
     const int i = S.order[k];
     float t;
     ++tests;
-    if(torus_hit<Real, DK>(S, i, r, tmin, min_(tmax, best), t))
+    if(torus_hit<Real, DK>(S, i, r, tmin, min_(tmax, best), t, wc))
     {
       best = t;
       id   = i;
@@ -600,10 +612,10 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
   return id;
 }
 
-// Any hit — the shadow query with gl_RayFlagsTerminateOnFirstHitEXT (REFL rchit:206-219).
+// Any hit — the shadow query with gl_RayFlagsTerminateOnFirstHitEXT (REFL/shaders/raytrace.rchit:114-131).
 template <class Real, bool DK = false>
 __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
-                                        uint32_t& tests)
+                                        uint32_t& tests, WorkCount& wc)
 {
   RayK<Real> r;
   r.set(o, d, tmin, tmax);
@@ -611,7 +623,7 @@ __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin,
   {
     float t;
     ++tests;
-    if(torus_hit<Real, DK>(S, S.order[k], r, tmin, tmax, t))
+    if(torus_hit<Real, DK>(S, S.order[k], r, tmin, tmax, t, wc))
       return true;
   }
   return false;

@@ -134,25 +134,26 @@ __device__ __forceinline__ void store_first_hit(const RenderArgs& a, size_t i_, 
 // atomics, then ONE global atomic per counter per block (65,536 waves adding to three words one
 // by one made the counted pass of the listed kernel 1.2 ms long).  Every thread of the block must
 // call it (it contains barriers); `stats` is kernel-uniform.
-__device__ __forceinline__ void block_add3(unsigned long long* stats, uint32_t v0, uint32_t v1, uint32_t v2)
+// Layout of the totals: trt_stats without `pixels` — [0] primary, [1] bounce, [2] shadow tests, [3] unused,
+// [4] traced, [5] solved tests, [6] evaluations.
+__device__ __forceinline__ void block_add_stats(unsigned long long* stats, uint32_t v0, uint32_t v1, uint32_t v2, const WorkCount& wc)
 {
-  __shared__ unsigned int acc[3];
-  if(threadIdx.x < 3) acc[threadIdx.x] = 0u;
+  __shared__ unsigned int acc[8];
+  if(threadIdx.x < 8) acc[threadIdx.x] = 0u;
   __syncthreads();
+  uint32_t v[6] = {v0, v1, v2, wc.traced, wc.solved, wc.evals};
   for(int off = 32; off > 0; off >>= 1)
-  {
-    v0 += __shfl_down(v0, off, 64);
-    v1 += __shfl_down(v1, off, 64);
-    v2 += __shfl_down(v2, off, 64);
-  }
+#pragma unroll
+    for(int k = 0; k < 6; ++k)
+      v[k] += __shfl_down(v[k], off, 64);
   if((threadIdx.x & 63) == 0)
   {
-    if(v0) atomicAdd(&acc[0], v0);
-    if(v1) atomicAdd(&acc[1], v1);
-    if(v2) atomicAdd(&acc[2], v2);
+#pragma unroll
+    for(int k = 0; k < 6; ++k)
+      if(v[k]) atomicAdd(&acc[k < 3 ? k : k + 1], v[k]);
   }
   __syncthreads();
-  if(threadIdx.x < 3 && acc[threadIdx.x])
+  if(threadIdx.x < 8 && acc[threadIdx.x])
     atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
@@ -192,13 +193,14 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
   stage_scene(&S, scene);
 
   uint32_t       tests  = 0;
+  WorkCount      wc;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.rays.n; i += stride)
   {
     const v3 o = {a.rays.ox[i], a.rays.oy[i], a.rays.oz[i]};
     const v3 d = {a.rays.dx[i], a.rays.dy[i], a.rays.dz[i]};
     float     t;
-    const int id = closest_hit<Real, DK>(S, o, d, a.tmin, a.tmax, t, tests);
+    const int id = closest_hit<Real, DK>(S, o, d, a.tmin, a.tmax, t, tests, wc);
     v3 P = {0.0f, 0.0f, 0.0f}, N = {0.0f, 0.0f, 0.0f};
     if(id >= 0)
     {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
     if(a.hits.id) a.hits.id[i] = id;
   }
   if(a.stats)
-    block_add3(a.stats, tests, 0u, 0u);
+    block_add_stats(a.stats, tests, 0u, 0u, wc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
 // miss and shadow-miss shaders inlined (REFL/shaders/raytrace.rgen:40-88).
 template <class Real, bool DK>
 __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a, uint32_t x, uint32_t y, uint32_t ly,
-                                            uint32_t& n_primary, uint32_t& n_bounce, uint32_t& n_shadow)
+                                            uint32_t& n_primary, uint32_t& n_bounce, uint32_t& n_shadow, WorkCount& wc)
 {
   const size_t oi = out_index(a, x, y, ly);
   v3 origin, direction;
@@ -244,7 +246,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
   {
     v3    prdHit, nextO = origin, nextD = direction;
     float t;
-    const int id = closest_hit<Real, DK>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce);
+    const int id = closest_hit<Real, DK>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce, wc);
     if(id < 0)
     {
       prdHit = {a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f};  // rmiss:37
@@ -271,7 +273,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
       }
       bool shadowed = false;
       if(h.wantShadow)
-        shadowed = any_hit<Real, DK>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow);  // rchit:114-131
+        shadowed = any_hit<Real, DK>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow, wc);  // rchit:114-131
       prdHit = hit_end(S, h, direction, shadowed, attenuation, done, nextO, nextD);
     }
     hitValue.x = fma_(prdHit.x, attenuation.x, hitValue.x);                // rgen:76
@@ -304,11 +306,12 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
   const uint32_t x  = (tile % tiles_x) * TW + (lane % TW);
   const uint32_t ly = (tile / tiles_x) * TH + (lane / TW);
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
+  WorkCount wc;
   if(x < a.W && ly < a.n_local_rows)
-    trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+    trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow, wc);
   if(a.stats)
   {
-    block_add3(a.stats, n_primary, n_bounce, n_shadow);
+    block_add_stats(a.stats, n_primary, n_bounce, n_shadow, wc);
   }
 }
 
@@ -459,6 +462,28 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
   return true;
 }
 
+// End of a classification block.  The list lengths are accumulated in a.counters[0..1] (zero when the
+// kernel starts); every block takes a ticket on a.counters[2] once its two reservations have
+// returned, and the block that draws the LAST ticket — every other block's additions are then
+// performed — moves the totals to a.counts (what the render kernels read) and leaves all three
+// accumulators zero for the next frame.  A frame therefore depends on no other frame: no memset, no
+// double buffering, nothing that distinguishes eager launches from hipGraph replays.  One returning
+// atomic per block (256 blocks at 4096²).
+__device__ __forceinline__ void classify_publish(const RenderArgs& a)
+{
+  if(threadIdx.x == 0)   // the reservations of threads 0 and 1 returned before the barrier above
+  {
+    const unsigned int ticket = atomicAdd(&a.counters[2], 1u);
+    if(ticket == gridDim.x - 1)
+    {
+      const unsigned int n_live = atomicExch(&a.counters[0], 0u), n_clear = atomicExch(&a.counters[1], 0u);
+      a.counts[0] = n_live < a.cap_live ? n_live : a.cap_live;
+      a.counts[1] = n_clear < a.cap_clear ? n_clear : a.cap_clear;
+      atomicExch(&a.counters[2], 0u);
+    }
+  }
+}
+
 constexpr int kClassifyThreads = 256;
 constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8×8 tiles = 32×8 pixels
 
@@ -476,11 +501,6 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  // The list counters are double-buffered: this frame counts in a.queue, and zeroes the set
-  // the NEXT frame will count in (no memset launch between frames; frames of one ctx are
-  // ordered by the caller, include/trt.h).
-  if(t < 2)
-    a.queue_next[t] = 0u;
   const bool     valid = t < macro_x * tiles_y;
   const uint32_t mx = t % macro_x, ty = t / macro_x;
   const uint32_t tx0 = mx * kMacroTiles;
@@ -512,14 +532,17 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
       wave_cnt[threadIdx.x][w] = sum;  // exclusive prefix over the block's waves
       sum += c;
     }
-    block_base[threadIdx.x] = sum ? atomicAdd(&a.queue[threadIdx.x], sum) : 0u;
+    block_base[threadIdx.x] = sum ? atomicAdd(&a.counters[threadIdx.x], sum) : 0u;
   }
   __syncthreads();
-  if(clear)
-    a.tiles_clear[block_base[1] + wave_cnt[1][wave] + pre[1]] = tx0 | (ty << 16);
+  const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1];
+  if(clear && ic < a.cap_clear)
+    a.tiles_clear[ic] = tx0 | (ty << 16);
   const uint32_t il = block_base[0] + wave_cnt[0][wave] + pre[0];
   for(uint32_t j = 0; j < nlive; ++j)
-    a.tiles_live[il + j] = (tx0 + j) | (ty << 16);
+    if(il + j < a.cap_live)
+      a.tiles_live[il + j] = (tx0 + j) | (ty << 16);
+  classify_publish(a);
 }
 
 // Second, finer classification (RenderArgs::fine): one lane per 8×8 tile; four consecutive lanes are one MACRO tile (32×8 pixels: one 128-B line
@@ -542,11 +565,6 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(co
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  // The list counters are double-buffered: this frame counts in a.queue, and zeroes the set
-  // the NEXT frame will count in (no memset launch between frames; frames of one ctx are
-  // ordered by the caller, include/trt.h).
-  if(t < 2)
-    a.queue_next[t] = 0u;
   const uint32_t m = t / kMacroTiles, j = t % kMacroTiles;      // macro tile, tile inside it
   const uint32_t mx = m % macro_x, ty = m / macro_x;
   const uint32_t tx = mx * kMacroTiles + j;
@@ -584,13 +602,15 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(co
       wave_cnt[threadIdx.x][w] = sum;  // exclusive prefix over the block's waves
       sum += c;
     }
-    block_base[threadIdx.x] = sum ? atomicAdd(&a.queue[threadIdx.x], sum) : 0u;
+    block_base[threadIdx.x] = sum ? atomicAdd(&a.counters[threadIdx.x], sum) : 0u;
   }
   __syncthreads();
-  if(nclear)
-    a.tiles_clear[block_base[1] + wave_cnt[1][wave] + pre[1]] = tx | (ty << 16);
-  if(nlive)
-    a.tiles_live[block_base[0] + wave_cnt[0][wave] + pre[0]] = tx | (ty << 16) | (clear ? kTileMissFlag : 0u);
+  const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1], il = block_base[0] + wave_cnt[0][wave] + pre[0];
+  if(nclear && ic < a.cap_clear)
+    a.tiles_clear[ic] = tx | (ty << 16);
+  if(nlive && il < a.cap_live)
+    a.tiles_live[il] = tx | (ty << 16) | (clear ? kTileMissFlag : 0u);
+  classify_publish(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -687,8 +707,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   const int      n_tori  = S.n_tori;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
-  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)1));
+  // list lengths as published by the classification, never beyond the lists' capacity
+  const uint32_t n_live  = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)0)), a.cap_live);
+  const uint32_t n_clear = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)1)), a.cap_clear);
 
   // Queue state.  Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k caches the
   // wave's k-th entry of the current batch of 64 (one gather load per 64 tiles) and entries
@@ -727,6 +748,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   tst.found = false;
   bool inflight = false, unconsumed = false;
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
+  WorkCount wc;
 
   for(;;)
   {
@@ -895,10 +917,14 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         if(kind == K_SHADOW) ++n_shadow;
         else if(depth == 0) ++n_primary;
         else ++n_bounce;
+        ++wc.traced;
         // closest-hit queries end the interval of every later test at the closest hit so far
         if(tst.setup((Real)rk.ox, (Real)rk.oy, (Real)rk.oz, (Real)rk.dx, (Real)rk.dy, (Real)rk.dz, rk.dd, rk.inv_dd, (Real)rk.tmin,
                      (Real)(kind == K_CLOSEST ? min_(q_tmax, best_t) : q_tmax), torus_k<Real>(S, S.order[ti])))
+        {
           inflight = true;
+          ++wc.solved;
+        }
         else
           ++ti;  // culled by the bounding sphere / window: this test is a miss
       }
@@ -916,6 +942,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
       const bool slow = __any(inflight && !tst.iterating());
       if(inflight)
       {
+        ++wc.evals;
         inflight   = slow ? tst.step() : tst.step_iter();
         unconsumed = !inflight;
       }
@@ -940,7 +967,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 
   if(a.stats)
   {
-    block_add3(a.stats, n_primary, n_bounce, n_shadow);
+    block_add_stats(a.stats, n_primary, n_bounce, n_shadow, wc);
   }
 }
 
@@ -952,6 +979,13 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 // macro tiles.  The grid is several times larger than the number of resident blocks, so the
 // hardware workgroup dispatcher balances the (very uneven) tile costs; the clear stores of
 // blocks that finish early overlap the solve of the others.
+// Timing ablations (skip the CLEAR or the LIVE part of a frame) exist in -DTRT_TUNING builds only:
+// the release library has no switch that returns an incomplete image with TRT_OK.
+#ifdef TRT_TUNING
+#define TRT_SKIP(a, bit) ((a).debug_skip & (bit))
+#else
+#define TRT_SKIP(a, bit) false
+#endif
 #ifndef TRT_LISTED_WAVES
 #define TRT_LISTED_WAVES 5
 #endif
@@ -969,9 +1003,11 @@ __global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES
   const uint32_t lane    = threadIdx.x & 63;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t n_live  = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)0));
-  const uint32_t n_clear = __builtin_amdgcn_readfirstlane(ld1(a.queue, (size_t)1));
+  // list lengths as published by the classification, never beyond the lists' capacity
+  const uint32_t n_live  = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)0)), a.cap_live);
+  const uint32_t n_clear = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)1)), a.cap_clear);
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
+  WorkCount wc;
 
   // Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k prefetches the wave's k-th
   // entry of the current batch of 64 (one gather load per list per batch) and entries are
@@ -997,9 +1033,9 @@ __global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES
     // hoisted out of the loop they would be spilled, and a spill reload is a vector-memory load
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
-    if(i < my_clear && !(a.debug_skip & 1u) && !(a.debug_skip & 4u))
+    if(i < my_clear && !TRT_SKIP(a, 1u) && !TRT_SKIP(a, 4u))
       n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), ln) * (uint32_t)S.n_tori;
-    if(i < my_live && !(a.debug_skip & 2u))
+    if(i < my_live && !TRT_SKIP(a, 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
       const uint32_t x = tile_x(packed) * 8 + (ln & 7), ly = tile_y(packed) * 8 + (ln >> 3);
@@ -1016,10 +1052,11 @@ __global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES
           n_primary += (uint32_t)S.n_tori;
         }
         else
-          trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow);
+          trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow, wc);
       }
     }
   }
+#ifdef TRT_TUNING
   if(a.debug_skip & 4u)   // experiment: all clear tiles after the traced ones
     for(uint32_t i = 0; i < my_clear; ++i)
     {
@@ -1030,9 +1067,10 @@ __global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES
       }
       n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane) * (uint32_t)S.n_tori;
     }
-  if(STATS && a.stats)   // STATS = false: the three counters are dead code (3 VGPRs and their increments)
+#endif
+  if(STATS && a.stats)   // STATS = false: the counters are dead code (their VGPRs and increments vanish)
   {
-    block_add3(a.stats, n_primary, n_bounce, n_shadow);
+    block_add_stats(a.stats, n_primary, n_bounce, n_shadow, wc);
   }
 }
 
@@ -1077,13 +1115,14 @@ __global__ __launch_bounds__(256) void post_kernel(const float4* __restrict__ in
     post_pixel(in[i], i, f32_out, u8_out);
 }
 
-hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, hipStream_t stream)
+hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, const Tuning& tn,
+                       hipStream_t stream)
 {
   if(n == 0) return hipSuccess;
   // many short blocks (one pixel per lane up to 16.8 M pixels): measured 0.074 / 0.087 ms for
   // → rgba8 / → f32 at 4096² against 0.097 / 0.112 ms with 4–16 long-running blocks per CU
   uint64_t want = (n + 255) / 256, cap = (uint64_t)n_cus * 256;
-  if(const char* e = getenv("TRT_POST_BLOCKS_PER_CU")) cap = (uint64_t)n_cus * (uint64_t)atoll(e);
+  if(tn.post_blocks_per_cu) cap = (uint64_t)n_cus * tn.post_blocks_per_cu;
   if(cap == 0) cap = 1;
   hipLaunchKernelGGL(post_kernel, dim3((uint32_t)(want < cap ? want : cap)), dim3(256), 0, stream,
                      reinterpret_cast<const float4*>(in), n, reinterpret_cast<float4*>(f32_out),
@@ -1161,10 +1200,10 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(const unsigned long 
 
 hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp, uint32_t W, uint32_t H,
                         const float* clear, float point_size, unsigned long long* keys, float* rgba, int n_cus,
-                        hipStream_t stream)
+                        const Tuning& tn, hipStream_t stream)
 {
   uint64_t npx = (uint64_t)W * H, cap = (uint64_t)n_cus * 16;
-  if(const char* e = getenv("TRT_SPLAT_BLOCKS_PER_CU")) cap = (uint64_t)n_cus * (uint64_t)atoll(e);
+  if(tn.splat_blocks_per_cu) cap = (uint64_t)n_cus * tn.splat_blocks_per_cu;
   if(cap == 0) cap = 1;
   auto grid = [&](uint64_t n) { const uint64_t w = (n + 255) / 256; return dim3((uint32_t)(w < cap ? (w ? w : 1) : cap)); };
   hipLaunchKernelGGL(splat_clear_kernel, grid(npx), dim3(256), 0, stream, keys, npx);
@@ -1183,13 +1222,13 @@ hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream)
+hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, const Tuning& tn, hipStream_t stream)
 {
   if(a.rays.n == 0)
     return hipSuccess;
   const uint64_t want = (a.rays.n + 255) / 256;
   uint64_t cap = 256u * 16u;
-  if(const char* e = getenv("TRT_TRACE_BLOCKS")) cap = (uint64_t)atoll(e);
+  if(tn.trace_blocks) cap = tn.trace_blocks;
   if(cap == 0) cap = 1;
   const uint32_t grid = (uint32_t)(want < cap ? want : cap);
   if(scene.f64 && scene.dk) hipLaunchKernelGGL((trace_kernel<double, true>), dim3(grid), dim3(256), 0, stream, scene, a);
@@ -1199,17 +1238,43 @@ hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t str
   return hipGetLastError();
 }
 
-// Zeroes one set of tile-list counters (32 words) — used only while a stream is being captured
-// into a hipGraph, where the frame cannot rely on the host-ordered previous frame to do it.
-__global__ void zero_counters_kernel(unsigned int* q) { q[threadIdx.x] = 0u; }
+// Zeroes up to 64 words (the query counters of a counted launch) with a one-wave kernel: a kernel
+// node when the stream is being captured — the *_dev entry points put no memset node into a graph
+// (32 memset nodes between 64 kernel nodes faulted on replay under ROCm 7.2).
+__global__ void zero_words_kernel(unsigned int* q, uint32_t n) { if(threadIdx.x < n) q[threadIdx.x] = 0u; }
 
-hipError_t launch_zero_counters(unsigned int* queue, hipStream_t stream)
+hipError_t launch_zero_words(unsigned int* words, uint32_t n, hipStream_t stream)
 {
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(32), 0, stream, queue);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, stream, words, n);
   return hipGetLastError();
 }
 
-hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
+Tuning tuning_from_env()
+{
+  Tuning t;
+#ifdef TRT_TUNING
+  auto u64 = [](const char* name, uint64_t& v) { if(const char* e = getenv(name)) v = (uint64_t)atoll(e); };
+  auto i32 = [](const char* name, int& v) { if(const char* e = getenv(name)) v = atoi(e); };
+  auto u32 = [](const char* name, uint32_t& v) { if(const char* e = getenv(name)) v = (uint32_t)atoi(e); };
+  u32("TRT_MIN_BATCH", t.min_batch);
+  i32("TRT_FINE_CLASSIFY", t.fine);
+  if(getenv("TRT_NO_TILE_CULL")) t.no_tile_cull = 1;
+  u32("TRT_DEBUG_SKIP", t.debug_skip);
+  if(getenv("TRT_DEBUG_TILES")) t.debug_tiles = 1;
+  u64("TRT_PERSIST_BLOCKS", t.persist_blocks);
+  u64("TRT_LISTED_BLOCKS", t.listed_blocks);
+  u32("TRT_LISTED_THREADS", t.listed_threads);
+  i32("TRT_TILE", t.static_tile);
+  u64("TRT_TRACE_BLOCKS", t.trace_blocks);
+  u64("TRT_POST_BLOCKS_PER_CU", t.post_blocks_per_cu);
+  u64("TRT_SPLAT_BLOCKS_PER_CU", t.splat_blocks_per_cu);
+  i32("TRT_TRACE_VARIANT", t.trace_variant);
+  i32("TRT_SPLAT_VARIANT", t.splat_variant);
+#endif
+  return t;
+}
+
+hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus, const Tuning& tn,
                          hipStream_t stream)
 {
   if(a.n_local_rows == 0 || a.W == 0)
@@ -1228,7 +1293,7 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
                          dim3(kClassifyThreads), 0, stream, scene, a);
     // 2. resident grid: kPersistentBlocksPerCU blocks of 4 waves per CU, never more waves than tiles
     uint64_t cap = (uint64_t)n_cus * kPersistentBlocksPerCU;
-    if(const char* e = getenv("TRT_PERSIST_BLOCKS")) cap = (uint64_t)atoll(e);
+    if(tn.persist_blocks) cap = tn.persist_blocks;
     if(v == kRenderListed)
     {
       // one wave per 16 tiles (4096²: 16,384 blocks = 64 per CU): with ≈16 % of the tiles LIVE a
@@ -1236,9 +1301,8 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       // single tiles and compute/store phases of different blocks interleave on every CU
       // (measured optimum at 2048², 4096² and 8192²; 8,192 blocks cost +25 % at 4096²)
       uint64_t lcap = tiles / 16 > (uint64_t)n_cus * 4 ? tiles / 16 : (uint64_t)n_cus * 4;
-      if(const char* e = getenv("TRT_LISTED_BLOCKS")) lcap = (uint64_t)atoll(e);
-      uint32_t bthreads = 256;
-      if(const char* e = getenv("TRT_LISTED_THREADS")) bthreads = (uint32_t)atoi(e);
+      if(tn.listed_blocks) lcap = tn.listed_blocks;
+      uint32_t bthreads = tn.listed_threads;
       if(bthreads != 64 && bthreads != 128) bthreads = 256;   // __launch_bounds__(256): nothing larger may be launched
       const uint32_t wpb = bthreads / 64;
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
@@ -1264,8 +1328,7 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
     return hipGetLastError();
   }
   // wave tile shape of the static kernel: TRT_TILE = 8x8 (default) | 16x4 | 32x2 | 64x1
-  int tw = 8;
-  if(const char* e = getenv("TRT_TILE")) tw = atoi(e);
+  int tw = tn.static_tile;
   if(tw != 8 && tw != 16 && tw != 32 && tw != 64) tw = 8;
   const uint64_t stiles = (uint64_t)((a.W + tw - 1) / tw) * ((a.n_local_rows + 64 / tw - 1) / (64 / tw));
   const uint32_t grid = (uint32_t)((stiles + 3) / 4);

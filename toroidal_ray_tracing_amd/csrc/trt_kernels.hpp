@@ -25,17 +25,42 @@ struct RenderArgs {
   trt_hits           hits;      // SoA depth-0 hit record, y*W+x  (optional streams)
   trt_rendered_data* rendered;  // AoS, x*H+y                     (BEF rgen:72-73,111-112)
   unsigned long long* stats;    // [4]: primary, bounce, shadow tests, pixels (optional)
-  // persistent kernel: tile lists built by tile_classify_kernel (packed tx | ty << 16)
-  unsigned int*       queue;        // [0] = #LIVE tiles, [1] = #CLEAR macro tiles of this frame (zero on entry)
-  unsigned int*       queue_next;   // the counter set of the next frame, zeroed by this one
+  // tile lists built by tile_classify*_kernel (packed tx | ty << 16 [| miss flag])
+  unsigned int*       counters;     // accumulators of the classification: [0] LIVE, [1] CLEAR, [2] blocks done.
+                                    // Zero between frames: the LAST classification block of a frame publishes the
+                                    // totals to `counts` and resets them (no memset, no double buffering: a frame
+                                    // depends on no other frame, eager or replayed from a hipGraph)
+  unsigned int*       counts;       // [0] = #LIVE tiles, [1] = #CLEAR macro tiles of this frame (written, never added to)
   uint32_t*           tiles_live;   // tiles that need ray tracing
-  uint32_t*           tiles_clear;  // tiles whose every pixel misses every bounding sphere
+  uint32_t*           tiles_clear;  // macro tiles whose every pixel provably misses
+  uint32_t            cap_live;     // capacity of tiles_live / tiles_clear in entries: nothing indexes past them
+  uint32_t            cap_clear;
   uint32_t            min_batch;    // persistent kernel: lanes needed to run a shader/refill round (default 24)
   uint32_t            tile_cull;    // 0: classify every tile as LIVE
   uint32_t            fine;         // 1: classify per 8×8 tile with the distance-function march (toroidal camera)
-  uint32_t            debug_skip;   // diagnostics (TRT_DEBUG_SKIP): 1 = skip clear tiles, 2 = skip traced tiles
+  uint32_t            debug_skip;   // -DTRT_TUNING builds only (TRT_DEBUG_SKIP): 1 = skip clear tiles, 2 = skip traced tiles
   uint32_t            vec4_ok;      // W % 4 == 0 and all first-hit streams 16-B aligned: dwordx4 clears
 };
+
+// Launch-shape knobs.  The release library uses the defaults below; a -DTRT_TUNING build
+// (libtrt_tuning.so, tools/ only) reads each of them ONCE from the environment in trt_create.
+struct Tuning {
+  uint32_t min_batch          = 24;   // TRT_MIN_BATCH
+  int      fine               = -1;   // TRT_FINE_CLASSIFY: -1 = chosen per frame (camera model / eye position)
+  int      no_tile_cull       = 0;    // TRT_NO_TILE_CULL
+  uint32_t debug_skip         = 0;    // TRT_DEBUG_SKIP (timing ablations: the frame is then INCOMPLETE)
+  int      debug_tiles        = 0;    // TRT_DEBUG_TILES: print the list lengths after every frame (synchronises)
+  uint64_t persist_blocks     = 0;    // TRT_PERSIST_BLOCKS   (0 = default)
+  uint64_t listed_blocks      = 0;    // TRT_LISTED_BLOCKS
+  uint32_t listed_threads     = 256;  // TRT_LISTED_THREADS
+  int      static_tile        = 8;    // TRT_TILE
+  uint64_t trace_blocks       = 0;    // TRT_TRACE_BLOCKS
+  uint64_t post_blocks_per_cu = 0;    // TRT_POST_BLOCKS_PER_CU
+  uint64_t splat_blocks_per_cu = 0;   // TRT_SPLAT_BLOCKS_PER_CU
+  int      trace_variant      = -1;   // TRT_TRACE_VARIANT
+  int      splat_variant      = -1;   // TRT_SPLAT_VARIANT
+};
+Tuning tuning_from_env();   // defaults in the release build
 
 struct TraceArgs {
   trt_rays rays;
@@ -47,13 +72,14 @@ struct TraceArgs {
 enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1, kRenderListed = 2 };
 constexpr int kPersistentBlocksPerCU = 16;  // 4× the resident 4 blocks/CU: the dispatcher evens out the tile costs
 
-hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, hipStream_t stream);
+hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, const Tuning& tn,
+                       hipStream_t stream);
 hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp, uint32_t W, uint32_t H,
                         const float* clear, float point_size, unsigned long long* keys, float* rgba, int n_cus,
-                        hipStream_t stream);
-hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, hipStream_t stream);
-hipError_t launch_zero_counters(unsigned int* queue, hipStream_t stream);
-hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus,
+                        const Tuning& tn, hipStream_t stream);
+hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, const Tuning& tn, hipStream_t stream);
+hipError_t launch_zero_words(unsigned int* words, uint32_t n, hipStream_t stream);   // n <= 64
+hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus, const Tuning& tn,
                          hipStream_t stream);
 
 }  // namespace trt

@@ -6,22 +6,37 @@ pixels are independent (one raygen invocation per pixel, no inter-pixel communic
 raytrace.rgen), so the frame shards by rows with no exchange during the render.  The only
 collective is the all-gather of the finished framebuffer, and only when world_size > 1.
 
-Layout.  With N ranks and groups of G rows, rank p owns rows y with (y // G) % N == p and
-renders them into a COMPACT local buffer [H/N, W, 4] (``trt_tiling.compact = 1``): exactly
-the send buffer ``all_gather_into_tensor`` wants.  The gathered buffer [N, H/N, W, 4] is a
-row permutation of the image; ``deinterleave`` restores row-major order with one strided
-copy (view [N, H/(G·N), G, W, 4] → permute(1,0,2,3,4)).
-
-xGMI is point-to-point (7 links per GPU): a ring all-gather is bound by ONE link per step,
-so the gather is issued as ONE large collective per frame (RCCL then spreads channels over
-all links) instead of many small per-band ones.
+Layout.  With N ranks and groups of G rows, rank p owns the rows y with (y // G) % N == p and
+renders them into a COMPACT local buffer [H/N, W, 4] (``trt_tiling.compact = 1``).  One *cycle*
+of the tiling is N consecutive groups = G·N consecutive image rows, group p of it coming from
+rank p — so the all-gather of the ranks' c-th groups, ``all_gather_into_tensor(frame[c·G·N :
+(c+1)·G·N], local[c·G : (c+1)·G])``, lands every row AT ITS PLACE in the row-major frame: the
+gathered frame needs no de-interleaving copy (round 1 paid 2 × 268 MB of HBM traffic per frame
+for one).  G is chosen so that a frame has a handful of cycles (default 8): few, large
+collectives (xGMI is point-to-point, 7 links per GPU; RCCL spreads a large collective over all
+of them) and still an interleaving fine enough to balance the load (the torus sits in the
+middle rows).
 """
 import torch
 import torch.distributed as dist
 
 from . import abi
 
-DEFAULT_GROUP_ROWS = 8   # one 8-row tile band: matches the kernels' 8×8 wave tiles
+DEFAULT_CYCLES = 8   # collectives per frame (when H allows it)
+
+
+def default_group_rows(H, world, cycles=DEFAULT_CYCLES):
+    """Largest number of cycles <= `cycles` for which the groups are whole 8-row tile bands
+    (tile culling needs groups of 8k rows); falls back to one band per rank."""
+    if world <= 1:
+        return H
+    for c in range(cycles, 0, -1):
+        if H % (world * c) == 0 and (H // (world * c)) % 8 == 0:
+            return H // (world * c)
+    for c in range(cycles, 0, -1):
+        if H % (world * c) == 0:
+            return H // (world * c)
+    raise ValueError(f"H={H} is not a multiple of the number of ranks {world}")
 
 
 def owned_rows(H, group_rows, n_parts, part):
@@ -30,8 +45,9 @@ def owned_rows(H, group_rows, n_parts, part):
 
 
 def deinterleave(gathered, H, W, group_rows, n_parts, channels=4):
-    """[N, H/N, W, C] gathered compact buffers → row-major [H, W, C] image (a strided view;
-    call .contiguous() / copy_ to materialise).  Requires H % (group_rows*n_parts) == 0."""
+    """[N, H/N, W, C] stacked compact buffers → row-major [H, W, C] image (a strided view).
+    Not used by TiledFrame any more (its gathers land in place); kept for callers that stack
+    compact parts themselves (tests).  Requires H % (group_rows*n_parts) == 0."""
     cycles = H // (group_rows * n_parts)
     v = gathered.view(n_parts, cycles, group_rows, W, channels)
     return v.permute(1, 0, 2, 3, 4).reshape(H, W, channels)
@@ -40,26 +56,30 @@ def deinterleave(gathered, H, W, group_rows, n_parts, channels=4):
 class TiledFrame:
     """Framebuffer + first-hit streams of one rank, and the per-frame render/gather step.
 
-    With world > 1 the step is software-pipelined over two buffer sets: the all-gather of
-    frame k (RCCL, asynchronous on the process group's stream) runs while frame k+1 renders, so
-    the frame rate is max(render, gather) instead of their sum; ``finish()`` drains the pipe.
+    With world > 1 the step is software-pipelined over two buffer sets: the all-gathers of
+    frame k (RCCL, asynchronous on the process group's stream) run while frame k+1 renders, so
+    the frame rate is max(render, gather) instead of their sum; ``finish()`` drains the pipe and
+    returns the last complete row-major frame.
     """
 
-    def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=DEFAULT_GROUP_ROWS,
-                 gather=True):
+    def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=None,
+                 gather=True, force_collective=False):
         """gather: True / "fp32" — all-gather the rgba32f framebuffer (default, what north_star
         prescribes); "rgba8" — tonemap each rank's rows (trt_post_dev, post.frag) and all-gather
         the 8-bit image a swapchain would present: 4x fewer bytes over xGMI, the rgba32f image
-        stays sharded; False / "none" — no collective."""
+        stays sharded; False / "none" — no collective.  force_collective: issue the collective
+        even when world == 1 (exercises the RCCL path on a one-GPU box)."""
         self.tr, self.W, self.H, self.world, self.rank = tracer, W, H, world, rank
         mode = {True: "fp32", False: "none"}.get(gather, gather)
         if mode not in ("fp32", "rgba8", "none"):
             raise ValueError(f"gather={gather!r}")
-        self.mode = mode if world > 1 else "none"
-        self.group_rows, self.gather = group_rows, self.mode != "none"
-        if world > 1 and H % (group_rows * world) != 0:
-            raise ValueError(f"H={H} must be a multiple of group_rows*world={group_rows * world}")
-        self.tiling = abi.trt_tiling(group_rows, world, rank, 1 if world > 1 else 0)
+        self.mode = mode if (world > 1 or force_collective) else "none"
+        self.gather = self.mode != "none"
+        self.group_rows = group_rows or default_group_rows(H, world)
+        if world > 1 and H % (self.group_rows * world) != 0:
+            raise ValueError(f"H={H} must be a multiple of group_rows*world={self.group_rows * world}")
+        self.cycles = H // (self.group_rows * world) if world > 1 else 1
+        self.tiling = abi.trt_tiling(self.group_rows, world, rank, 1 if world > 1 else 0)
         self.local_rows = tracer.tiling_rows(self.tiling, H) if world > 1 else H
         self.local_pixels = self.local_rows * W
         f32 = dict(dtype=torch.float32, device=device)
@@ -68,35 +88,43 @@ class TiledFrame:
         self.hits = {k: torch.empty(self.local_pixels, **f32) for k in want_hits if k != "id"}
         if "id" in want_hits:
             self.hits["id"] = torch.empty(self.local_pixels, dtype=torch.int32, device=device)
-        # concatenated along dim 0 (the form both RCCL and gloo accept); viewed as [N, H/N, W, 4]
         gdt = dict(dtype=torch.uint8 if self.mode == "rgba8" else torch.float32, device=device)
         self.sends = [torch.empty(self.local_rows, W, 4, **gdt) for _ in range(nbuf)] if self.mode == "rgba8" else self.locals
-        self.gathered = [torch.empty(world * self.local_rows, W, 4, **gdt) for _ in range(nbuf)] if self.gather else None
-        self.full = torch.empty(H, W, 4, **gdt) if self.gather else self.locals[0]
-        self._pending = [None] * nbuf   # in-flight all-gather of each buffer set
+        # the gathered frame, row-major [H, W, 4] — one per buffer set (frame k+1 is gathered while
+        # a consumer may still read frame k)
+        self.fulls = [torch.empty(H, W, 4, **gdt) for _ in range(nbuf)] if self.gather else self.locals
+        self._pending = [[] for _ in range(nbuf)]   # in-flight all-gathers of each buffer set
         self._k = 0
+        self._last = 0
 
     @property
     def local(self):
         return self.locals[0]
 
+    @property
+    def full(self):
+        """The most recent complete frame (after ``finish()``: the last one rendered)."""
+        return self.fulls[self._last]
+
     def describe(self):
-        if self.world == 1:
+        if self.world == 1 and not self.gather:
             return "single GPU, full frame"
         what = {"fp32": "all_gather_into_tensor(rgba32f)", "rgba8": "post pass + all_gather_into_tensor(rgba8)"}.get(self.mode)
-        return (f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; "
-                f"{what + ' pipelined behind the next frame + de-interleave' if self.gather else 'no gather'}")
+        tail = (f"{self.cycles} x {what} per frame, each landing in place in the row-major frame, pipelined behind the next frame"
+                if self.gather else "no gather")
+        return f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; {tail}"
 
     def _retire(self, b):
-        """Wait for the gather of buffer set b and assemble its frame."""
-        if self._pending[b] is not None:
-            self._pending[b].wait()   # orders the current stream behind the collective
-            self._pending[b] = None
-            self.full.copy_(deinterleave(self.gathered[b], self.H, self.W, self.group_rows, self.world))
+        """Wait for the gathers of buffer set b: its row-major frame is then complete."""
+        if self._pending[b]:
+            for w in self._pending[b]:
+                w.wait()   # orders the current stream behind the collective
+            self._pending[b] = []
+            self._last = b
 
     def render(self, scene, g, pc, camera, stream, events=None):
-        """One frame: render this rank's rows; when world > 1 start the all-gather of this frame
-        and finish (wait + de-interleave) the frame that used this buffer set two steps ago.
+        """One frame: render this rank's rows; when gathering, start the all-gathers of this frame
+        and retire the frame that used this buffer set two steps ago.
         `events` = (start, end) torch.cuda.Events recorded around the render launches only."""
         hp = {k: v.data_ptr() for k, v in self.hits.items()}
         b = self._k % len(self.locals)
@@ -117,12 +145,17 @@ class TiledFrame:
             self.tr.post_dev(self.locals[b].data_ptr(), self.local_pixels, 0, self.sends[b].data_ptr(),
                              stream=stream.cuda_stream)
         if self.gather:
-            self._pending[b] = dist.all_gather_into_tensor(self.gathered[b], self.sends[b], async_op=True)
-        return self.full
+            G, span = self.group_rows if self.world > 1 else self.H, (self.group_rows * self.world if self.world > 1 else self.H)
+            for c in range(self.cycles):
+                self._pending[b].append(dist.all_gather_into_tensor(
+                    self.fulls[b][c * span:(c + 1) * span], self.sends[b][c * G:(c + 1) * G], async_op=True))
+        else:
+            self._last = b
+        return self.fulls[b]
 
     def finish(self):
-        """Drain the pipeline: every frame rendered so far is gathered and assembled."""
+        """Drain the pipeline: every frame rendered so far is gathered; returns the last one."""
         if self.gather:
-            for b in range(len(self.locals)):
-                self._retire((self._k + b) % len(self.locals))
+            for i in range(len(self.locals)):
+                self._retire((self._k + i) % len(self.locals))
         return self.full

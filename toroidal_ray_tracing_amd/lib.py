@@ -42,6 +42,7 @@ SYMBOLS = {
     "trt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(abi.trt_stats)]),
     "trt_set_render_variant": (C.c_int, [C.c_void_p, C.c_char_p]),
     "trt_get_render_variant": (C.c_char_p, [C.c_void_p]),
+    "trt_set_classification": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

@@ -60,6 +60,10 @@ class Tracer:
     def set_render_variant(self, name):
         self._check(self._L.trt_set_render_variant(self._h, name.encode()))
 
+    def set_classification(self, level):
+        """abi.TRT_CLASSIFY_AUTO (-1) | _MACRO (0) | _TILE (1): level of the tile classification."""
+        self._check(self._L.trt_set_classification(self._h, int(level)))
+
     def render_variant(self):
         return self._L.trt_get_render_variant(self._h).decode()
 
@@ -69,7 +73,7 @@ class Tracer:
     def stats(self):
         st = abi.trt_stats()
         self._check(self._L.trt_get_stats(self._h, C.byref(st)))
-        return {k: int(getattr(st, k)) for k in ("primary_tests", "bounce_tests", "shadow_tests", "pixels")}
+        return {k: int(getattr(st, k)) for k in abi.STAT_FIELDS}
 
     # -- trace(rays_in -> hits_out) ----------------------------------------------------
     def trace(self, scene, o, d, tmin=0.001, tmax=10000.0):
