@@ -234,18 +234,26 @@ def test_durand_kerner_not_in_persistent_variant(tr):
         tr.set_render_variant("listed")
 
 
-@pytest.mark.parametrize("name,cam", [("render_pinhole_mirror", 0), ("render_toroidal_plastic", 1)])
-def test_render_vs_golden(tr, name, cam):
+@pytest.mark.parametrize("name,cam,prec", [("render_pinhole_mirror", 0, abi.TRT_SOLVE_F32),
+                                           ("render_pinhole_nested_f64", 0, abi.TRT_SOLVE_F64),
+                                           ("render_toroidal_plastic", 1, abi.TRT_SOLVE_F32)])
+def test_render_vs_golden(tr, name, cam, prec):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     W = H = 64
     pc = camera.baseline_push(5)
-    if cam == 0:
+    if name == "render_pinhole_mirror":
         sc, g = camera.single_torus_scene(), camera.baseline_camera(W, H)
+    elif name == "render_pinhole_nested_f64":   # the BASELINE config 4 shape: 8 nested tori, FP64 solve
+        sc, g = camera.nested_tori_scene(), camera.baseline_camera(W, H)
     else:
         sc = camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC)
         g = camera.toroidal_camera(W, H)
         pc.rho = 4.0
-    rgba, hits = tr.render(sc, g, pc, W, H, cam)
+    tr.set_solver(prec)
+    try:
+        rgba, hits = tr.render(sc, g, pc, W, H, cam)
+    finally:
+        tr.set_solver(abi.TRT_SOLVE_F32)
     np.testing.assert_allclose(rgba, z["rgba"], rtol=1e-5, atol=1e-6)
     np.testing.assert_array_equal(np.isfinite(hits["t"]), np.isfinite(z["hit_t"]))
     np.testing.assert_array_equal(hits["id"], z["hit_id"])
@@ -331,6 +339,150 @@ def test_full_size_properties(tr, variant):
     csum = {k: int(v.view(torch.int32).long().sum().item()) for k, v in hb.items()}
     prev = test_full_size_properties.__dict__.setdefault("csum", csum)
     assert prev == csum
+
+
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
+def test_config4_full_size_properties(tr, variant):
+    """BASELINE config 4 at full size (8 nested tori r = 0.05…0.40 around R = 1, 4096², maxDepth 5, FP64 root
+    solve, FP32 I/O) through oracle-free properties: the first hit is always the OUTERMOST shell seen from outside
+    (id 7), every hit point lies on the shell its id names, normals are unit and face the ray, t = |P - eye|,
+    misses carry the miss record, and the three kernel variants agree bit for bit (checksum of every stream)."""
+    import torch
+    W = H = 4096
+    sc, g, pc = camera.nested_tori_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
+    dev = torch.device("cuda:0")
+    rgba = torch.empty(H, W, 4, device=dev)
+    hb = {k: torch.empty(H * W, device=dev) for k in GEOM}
+    hid = torch.empty(H * W, dtype=torch.int32, device=dev)
+    tr.set_render_variant(variant)
+    tr.set_solver(abi.TRT_SOLVE_F64)
+    tr.enable_stats(True)
+    try:
+        tr.render_dev(sc, g, pc, W, H, rgba.data_ptr(),
+                      hit_ptrs={**{k: v.data_ptr() for k, v in hb.items()}, "id": hid.data_ptr()},
+                      stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = tr.stats()
+    finally:
+        tr.enable_stats(False)
+        tr.set_solver(abi.TRT_SOLVE_F32)
+        tr.set_render_variant("listed")
+    hit = hid >= 0
+    assert 0.08 < hit.float().mean().item() < 0.5
+    assert (hid[hit] == 7).all()                      # the camera is outside: the r = 0.40 shell hides the others
+    P = torch.stack([hb["px"], hb["py"], hb["pz"]], 1)[hit].double()
+    N = torch.stack([hb["nx"], hb["ny"], hb["nz"]], 1)[hit].double()
+    rho = torch.hypot(P[:, 0], P[:, 2])
+    r_id = 0.05 * (hid[hit].double() + 1.0)
+    gval = (rho - 1.0) ** 2 + P[:, 1] ** 2 - (r_id.float().double()) ** 2
+    assert gval.abs().max().item() < 5e-6             # FP32 P = o + t·d: |g| ≈ 2 r · 1e-6
+    assert (N.norm(dim=1) - 1).abs().max().item() < 3e-7
+    eye = torch.tensor([0.0, 1.5, -4.0], dtype=torch.float64, device=dev)
+    D = P - eye
+    assert ((D * N).sum(1) <= 1e-6).all()
+    assert (D.norm(dim=1) - hb["t"][hit].double()).abs().max().item() < 2e-5
+    miss = ~hit
+    assert torch.isinf(hb["t"][miss]).all() and (hb["px"][miss] == 0).all() and (hb["nz"][miss] == 0).all()
+    img = rgba.view(-1, 4)
+    assert (img[miss][:, :3] == 0.8).all() and (img[:, 3] == 1).all() and torch.isfinite(img).all()
+    assert st["primary_tests"] == 8 * W * H and st["pixels"] == W * H and st["bounce_tests"] > 0 and st["shadow_tests"] > 0
+    csum = {k: int(v.view(torch.int32).long().sum().item()) for k, v in hb.items()}
+    csum["rgba"] = int(rgba.view(torch.int32).long().sum().item()) if variant != "x" else 0
+    csum["queries"] = (st["primary_tests"], st["bounce_tests"], st["shadow_tests"])
+    prev = test_config4_full_size_properties.__dict__.setdefault("csum", csum)
+    assert prev == csum
+
+
+def test_config5_shape_tiled_on_one_gpu(tr):
+    """BASELINE config 5's shape on ONE GPU: 8192², maxDepth 5, the 8 parts of `trt_tiling` (groups of 8 rows and the
+    default groups of 128 rows) rendered one after the other through trt_render_tiled_dev into compact buffers —
+    what the 8 ranks do.  The parts, put at their rows (the in-place gather of TiledFrame), equal the full-frame
+    render bit for bit; plus the oracle-free properties of test_full_size_properties on the assembled frame."""
+    import torch
+    from toroidal_ray_tracing_amd import distributed as trtd
+    W = H = 8192
+    parts = 8
+    sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    full = torch.empty(H, W, 4, device=dev)
+    t_full = torch.empty(H * W, device=dev)
+    id_full = torch.empty(H * W, dtype=torch.int32, device=dev)
+    tr.enable_stats(True)
+    try:
+        tr.render_dev(sc, g, pc, W, H, full.data_ptr(), hit_ptrs={"t": t_full.data_ptr(), "id": id_full.data_ptr()}, stream=s)
+        torch.cuda.synchronize()
+        st_full = tr.stats()
+        for group in (8, trtd.default_group_rows(H, parts)):
+            assert H % (group * parts) == 0
+            asm = torch.zeros(H, W, 4, device=dev)          # the frame as the in-place gathers assemble it
+            t_asm = torch.zeros(H, W, device=dev)
+            local = torch.empty(H // parts, W, 4, device=dev)
+            t_loc = torch.empty(H // parts, W, device=dev)
+            tot = {k: 0 for k in QUERY_KEYS}
+            span = group * parts
+            for p in range(parts):
+                tiling = abi.trt_tiling(group, parts, p, 1)
+                assert tr.tiling_rows(tiling, H) == H // parts
+                tr.render_tiled_dev(sc, g, pc, W, H, tiling, local.data_ptr(), hit_ptrs={"t": t_loc.data_ptr()}, stream=s)
+                torch.cuda.synchronize()
+                for k, v in q(tr.stats()).items():
+                    tot[k] += v
+                # all_gather_into_tensor(frame[c·span:(c+1)·span], local[c·group:(c+1)·group]) puts rank p's slice at offset p·group
+                asm.view(H // span, parts, group, W, 4)[:, p] = local.view(H // span, group, W, 4)
+                t_asm.view(H // span, parts, group, W)[:, p] = t_loc.view(H // span, group, W)
+            assert torch.equal(asm.view(torch.int32), full.view(torch.int32)), group
+            assert torch.equal(t_asm.view(-1).view(torch.int32), t_full.view(torch.int32)), group
+            assert tot == q(st_full), group
+            del asm, t_asm, local, t_loc
+    finally:
+        tr.enable_stats(False)
+    hit = id_full >= 0
+    assert 0.05 < hit.float().mean().item() < 0.5 and st_full["primary_tests"] == W * H
+    img = full.view(-1, 4)
+    assert (img[~hit][:, :3] == 0.8).all() and (img[:, 3] == 1).all() and torch.isfinite(img).all()
+    assert torch.isinf(t_full[~hit]).all() and (t_full[hit] > 2.0).all() and (t_full[hit] < 7.0).all()
+
+
+def test_rccl_collective_path_world_1(tr):
+    """The RCCL leg of TiledFrame on the one GPU there is: a world_size-1 `nccl` process group with the collective
+    FORCED (an all_gather_into_tensor over one rank is a device copy issued by RCCL), both gather modes, the two-deep
+    pipeline and finish().  Multi-rank correctness of the same class is covered on CPU over gloo
+    (tests/test_distributed.py); this one proves that the calls bench.py makes with N > 1 are accepted by RCCL on
+    device buffers of the shapes and dtypes used (contiguous row slices of the frame, fp32 and uint8)."""
+    import torch
+    import torch.distributed as dist
+    from toroidal_ray_tracing_amd import distributed as trtd
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    dev = torch.device("cuda:0")
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        W = H = 512
+        sc, g = camera.single_torus_scene(), camera.baseline_camera(W, H)
+        want = torch.empty(H, W, 4, device=dev)
+        stream = torch.cuda.current_stream()
+        tr.render_dev(sc, g, camera.baseline_push(3), W, H, want.data_ptr(), stream=stream.cuda_stream)
+        for mode in ("fp32", "rgba8"):
+            frame = trtd.TiledFrame(tr, W, H, 1, 0, dev, gather=mode, force_collective=True)
+            assert frame.gather and "all_gather_into_tensor" in frame.describe()
+            for depth in (1, 2, 3):
+                frame.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, stream)
+            full = frame.finish()
+            torch.cuda.synchronize()
+            if mode == "fp32":
+                assert torch.equal(full.view(torch.int32), want.view(torch.int32))
+            else:
+                w8 = torch.empty(H, W, 4, dtype=torch.uint8, device=dev)
+                tr.post_dev(want.data_ptr(), W * H, 0, w8.data_ptr(), stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                assert full.dtype == torch.uint8 and torch.equal(full, w8)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_trace_dev_full_size_matches_render(tr):

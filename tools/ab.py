@@ -2,7 +2,8 @@
 """Interleaved A/B timing of render variants in ONE process (cdna guide §5.4 rule 24).
 usage: tools_ab.py [--size 4096] [--depth 5] [--rounds 7] [--frames 10] variant[:ENV=VAL,...] ..."""
 import argparse, os, statistics, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402  (loads the -DTRT_TUNING build, see _tuning.py)
 import torch
 from toroidal_ray_tracing_amd import abi, camera
 from toroidal_ray_tracing_amd.tracer import Tracer
@@ -40,6 +41,7 @@ def run(spec, n):
         k, _, val = kv.partition("=")
         saved[k] = os.environ.get(k); os.environ[k] = val
     tr.set_render_variant(v)
+    _tuning.reload(tr)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
     for _ in range(n):
@@ -48,6 +50,7 @@ def run(spec, n):
     for k, old in saved.items():
         if old is None: os.environ.pop(k, None)
         else: os.environ[k] = old
+    _tuning.reload(tr)
     return e0.elapsed_time(e1) / n
 for spec in a.specs:
     run(spec, 3)

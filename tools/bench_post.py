@@ -1,5 +1,6 @@
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402  (loads the -DTRT_TUNING build, see _tuning.py)
 import torch
 from toroidal_ray_tracing_amd.tracer import Tracer
 dev = torch.device("cuda:0"); tr = Tracer(0); s = torch.cuda.current_stream()
@@ -16,7 +17,7 @@ def t(fn, reps=20, rounds=5):
         if r: out.append(e0.elapsed_time(e1) / reps)
     return statistics.median(out)
 for b in (4, 8, 16, 32, 64, 128, 256):
-    os.environ["TRT_POST_BLOCKS_PER_CU"] = str(b)
+    os.environ["TRT_POST_BLOCKS_PER_CU"] = str(b); _tuning.reload(tr)
     a = t(lambda: tr.post_dev(img.data_ptr(), n, 0, o8.data_ptr(), stream=s.cuda_stream))
     c = t(lambda: tr.post_dev(img.data_ptr(), n, of.data_ptr(), 0, stream=s.cuda_stream))
     print(f"blocks/CU {b:4d}: ->u8 {a:.4f} ms ({20*n/a/1e6:.0f} GB/s)   ->f32 {c:.4f} ms ({32*n/c/1e6:.0f} GB/s)")

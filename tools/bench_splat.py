@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Re-projection (trt_splat_dev) timing over grid sizes (TRT_SPLAT_BLOCKS_PER_CU)."""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402  (loads the -DTRT_TUNING build, see _tuning.py)
 import torch
 from toroidal_ray_tracing_amd import camera
 from toroidal_ray_tracing_amd.tracer import Tracer
@@ -23,9 +24,9 @@ def t(reps=5, rounds=4):
         if k: res.append(e0.elapsed_time(e1) / reps)
     return statistics.median(res)
 for b in (4, 16, 64, 256):
-    os.environ["TRT_SPLAT_BLOCKS_PER_CU"] = str(b)
+    os.environ["TRT_SPLAT_BLOCKS_PER_CU"] = str(b); _tuning.reload(tr)
     print(f"random points, blocks/CU {b:4d}: {t():.4f} ms")
-os.environ.pop("TRT_SPLAT_BLOCKS_PER_CU")
+os.environ.pop("TRT_SPLAT_BLOCKS_PER_CU"); _tuning.reload(tr)
 # the real pipeline: a 4096x2048 toroidal capture (points in the capture's x*H+y order) re-projected
 from toroidal_ray_tracing_amd import abi
 W, H = 4096, 2048

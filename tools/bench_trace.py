@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """trace(rays_in -> hits_out) timing over grid sizes (TRT_TRACE_BLOCKS): BASELINE config 2 rays and random aimed rays."""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402  (loads the -DTRT_TUNING build, see _tuning.py)
 import torch
 from toroidal_ray_tracing_amd import abi, camera
 from toroidal_ray_tracing_amd.tracer import Tracer
@@ -30,6 +31,6 @@ def t(rays, reps=20, rounds=5):
         if k: res.append(e0.elapsed_time(e1) / reps)
     return statistics.median(res)
 for b in (1024, 2048, 4096, 8192, 16384):
-    os.environ["TRT_TRACE_BLOCKS"] = str(b)
+    os.environ["TRT_TRACE_BLOCKS"] = str(b); _tuning.reload(tr)
     a, c = t(rays_a), t(rays_b)
     print(f"blocks {b:6d}: camera rays {a:.4f} ms ({52*n/a/1e6:.0f} GB/s)   aimed rays {c:.4f} ms ({52*n/c/1e6:.0f} GB/s)")

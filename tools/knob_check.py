@@ -2,7 +2,8 @@
 """Checks that experiment knobs (TRT_DEBUG_SKIP bits >= 8, other env) leave the frame bit-identical.
 usage: knob_check.py ENV=VAL[,ENV=VAL] ..."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402  (loads the -DTRT_TUNING build, see _tuning.py)
 import torch
 from toroidal_ray_tracing_amd import abi, camera
 from toroidal_ray_tracing_amd.tracer import Tracer
@@ -30,9 +31,11 @@ for name, sc, g, pc, cam in cases:
     for spec in sys.argv[1:]:
         kv = dict(x.split("=") for x in spec.split(","))
         os.environ.update(kv)
+        _tuning.reload(tr)
         got = frame(sc, g, pc, cam)
         for k in kv:
             os.environ.pop(k)
+        _tuning.reload(tr)
         same = all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(ref, got))
         print(f"{name:16s} {spec:32s} {'identical' if same else 'DIFFERENT'}")
         bad += not same

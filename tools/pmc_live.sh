@@ -5,6 +5,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmcl_$TAG; mkdir -p $OUT
 export TRT_DEBUG_SKIP=${TRT_DEBUG_SKIP-1}
+export TRT_LIB=$R/toroidal_ray_tracing_amd/libtrt_tuning.so   # the knobs exist in the -DTRT_TUNING build only
 rocprofv3 -L > $OUT/counters.txt 2>&1
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS" \
@@ -12,7 +13,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST
          "SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
          "GRBM_GUI_ACTIVE SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_IFETCH SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_BUSY_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/p$i.err || tail -3 $OUT/p$i.err
+  rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 3 --warmup 1 --frames-per-step 2 --no-secondary --no-cpu-baseline "$@" > /dev/null 2> $OUT/p$i.err || tail -3 $OUT/p$i.err
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
