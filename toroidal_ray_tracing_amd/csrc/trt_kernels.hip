@@ -112,6 +112,16 @@ __device__ __forceinline__ size_t out_index(const RenderArgs& a, uint32_t x, uin
   return (size_t)(a.compact ? ly : y) * a.W + x;
 }
 
+// The id of a miss, materialised at the store: as a plain constant hipcc hoists (-1,-1,-1,-1) out of the
+// tile loop, keeps it live across the whole solve and — in the FP64 kernels at 128 VGPRs — spills it
+// (20 B of scratch whose every reload is a vector-memory load that drains the output stores).
+__device__ __forceinline__ int miss_id()
+{
+  int m;
+  asm volatile("v_mov_b32 %0, -1" : "=v"(m));
+  return m;
+}
+
 __device__ __forceinline__ void store_first_hit(const RenderArgs& a, size_t i_, float t, v3 P, v3 N, int id)
 {
   // The pixel index passes through an opaque copy so that the eight stream addresses are formed
@@ -252,7 +262,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
       prdHit = {a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f};  // rmiss:37
       if(depth == 0)
       {
-        store_first_hit(a, oi, t, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);  // BEF rmiss:21
+        store_first_hit(a, oi, t, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, miss_id());  // BEF rmiss:21
         if(rd)
         {
           // materialised here: hoisted out of the tile loop this constant vector gets spilled
@@ -683,13 +693,17 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
     if(a.hits.nx) st4(a.hits.nx + i, zv);
     if(a.hits.ny) st4(a.hits.ny + i, zv);
     if(a.hits.nz) st4(a.hits.nz + i, zv);
-    if(a.hits.id) st4(a.hits.id + i, -1, -1, -1, -1);
+    if(a.hits.id)
+    {
+      const int m = miss_id();
+      st4(a.hits.id + i, m, m, m, m);
+    }
   }
   else
   {
     for(uint32_t k = 0; k < 4; ++k)
       if(xs + k < a.W)
-        store_first_hit(a, row + xs + k, inf, {zero, zero, zero}, {zero, zero, zero}, -1);
+        store_first_hit(a, row + xs + k, inf, {zero, zero, zero}, {zero, zero, zero}, miss_id());
   }
   return n;
 }
@@ -792,7 +806,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
             have_prd = true;
             if(depth == 0)
             {
-              store_first_hit(a, oi, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);
+              store_first_hit(a, oi, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, miss_id());
               if(rd) st4(rd, make_float4(0.0f, 0.0f, 0.0f, 1.0f));
             }
           }
@@ -992,8 +1006,10 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 #ifndef TRT_LISTED_WAVES_F64
 #define TRT_LISTED_WAVES_F64 4
 #endif
+// Waves per SIMD the register allocation aims at.  The counted (STATS) instantiations carry six
+// counters per lane and run only in the untimed counted pass: they get one wave less instead of scratch.
 template <class Real, bool STATS, bool DK>
-__global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64)) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
+__global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64) - (STATS ? 1 : 0))) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
 {
   __shared__ SceneK     S;
   __shared__ RenderArgs A_lds;
@@ -1046,7 +1062,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : sizeof(Real) == 4 ? TRT_LISTED_WAVES
           // classified "every ray of this tile misses": the miss record of trace_pixel, no tracing
           // (rmiss:37 → rgen:76 with attenuation 1 → rgen:87; BEF rmiss:21)
           const size_t oi = out_index(a, x, image_row(a, ly), ly);
-          store_first_hit(a, oi, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, -1);
+          store_first_hit(a, oi, __builtin_inff(), {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, miss_id());
           if(a.rgba)
             st4(a.rgba + 4 * oi, make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, 1.0f));
           n_primary += (uint32_t)S.n_tori;
