@@ -330,6 +330,76 @@ struct TorusTest {
   // true when step_iter() applies to this lane
   __device__ __forceinline__ bool iterating() const { return mode == M_FWD || mode == M_BWD; }
 
+  // The same walk as step()/step_iter() — same evaluation points, same decisions, hence the same
+  // root bit for bit — written as NESTED loops for a lane that owns its test from start to finish
+  // (trace, listed and static kernels): an outer loop over the <= 3 pieces of constant sign of f'',
+  // an inner Newton loop that serves the forward run (from A, while sign f = sigma) and the backward
+  // run (from B, onto the single root of a piece with a sign change) with ONE body: a trip is the
+  // evaluation, the division and five compares (~40 issue slots) instead of the ~170 of the general
+  // transition table of step(), and the piece bookkeeping runs once per piece instead of once per
+  // trip.  Lanes of a wave in different pieces still share the inner loop.  `evals` counts (f, f').
+  // Call after a successful setup(); then finish().
+  __device__ __forceinline__ void walk(uint32_t& evals)
+  {
+    const Real A4x4 = Real(4) * A4, P2x2 = Real(2) * P2;
+    auto eval = [&](Real u, Real& f, Real& d) {
+      const Real e1 = fma_(A4 * u, u, P2);
+      const Real e2 = fma_(e1, u, Q1);
+      f = fma_(e2, u, S0);
+      const Real g1 = fma_(A4x4 * u, u, P2x2);
+      d = fma_(g1, u, Q1);
+    };
+    Real a = A, fa, da;          // setup() leaves the window start in A
+    eval(a, fa, da);
+    ++evals;
+    found = false;
+    root  = Real(0);
+    mode  = M_DONE;
+    for(;;)
+    {
+      const bool c1 = split && a < -w, c2 = split && a < w;
+      const Real b  = c1 ? min_(-w, hi) : (c2 ? min_(w, hi) : hi);
+      const Real sg = (c2 && !c1) ? Real(-1) : Real(1);          // sign of f'' on the piece
+      if(fa == Real(0)) { found = true; root = a; break; }       // the piece end is itself a root
+      const bool bwd = (fa > Real(0)) != (sg > Real(0));         // sign f(A) = -sigma: probe B
+      Real x = a, fx = fa, dx = da;
+      bool pos = fa > Real(0);                                   // the sign the run must keep
+      bool run = true, noroot = false;
+      if(bwd)
+      {
+        eval(b, fx, dx);
+        ++evals;
+        x = b;
+        if(fx == Real(0)) { found = true; root = b; break; }     // (oracle: sb = sigma, first check of the run)
+        pos = fx > Real(0);
+        if(pos != (sg > Real(0))) { run = false; noroot = true; }  // no sign change: no root in the piece
+      }
+      if(run)
+      {
+        const Real ustop = (b - a) * kStepStop;
+        const Real sd    = bwd ? -sg : sg;      // forward needs sigma·f' < 0, backward sigma·f' > 0
+        const Real lim   = bwd ? -a : b;        // forward: xn < B; backward: xn > A  ⇔  -xn < -A
+        for(int it = 0; it < kNewtonCap; ++it)
+        {
+          if(!(sd * dx < Real(0))) { noroot = !bwd; break; }                 // forward: no root ahead; backward: stop here
+          const Real st = fx / dx;
+          const Real xn = x - st;
+          if(!((bwd ? -xn : xn) < lim)) { noroot = !bwd; if(bwd) x = a; break; }
+          if(xn == x) break;
+          x = xn;
+          if(abs_(st) <= ustop) break;
+          eval(x, fx, dx);
+          ++evals;
+          if(fx == Real(0) || (fx > Real(0)) != pos) break;
+        }
+        if(!noroot) { found = true; root = x; break; }
+      }
+      if(!(b < hi)) break;                       // that was the last piece: a miss
+      if(!bwd) { eval(b, fx, dx); ++evals; }     // (a failed probe has evaluated B already)
+      a = b; fa = fx; da = dx;
+    }
+  }
+
   // T2, alternative solver (TRT_SOLVE_DK_*): Durand–Kerner iteration on the monic depressed
   // quartic u⁴ + p·u² + q·u + s — four complex iterates from the spiral (0.4+0.9i)^k scaled by the
   // bounding-sphere radius, updated in place for a FIXED number of sweeps (every lane runs the
@@ -515,9 +585,16 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
 {
   TorusTest<Real> q;
   ++wc.traced;
+#if defined(TRT_ABLATE) && TRT_ABLATE == 2   // timing ablation builds only (never shipped): no test at all
+  return false;
+#endif
   if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))
     return false;
   ++wc.solved;
+#if defined(TRT_ABLATE) && TRT_ABLATE == 1   // … setup only, no walk
+  t_out = q.hi;
+  return q.hi > Real(1e30);
+#endif
   if(DK)
   {
     if(alt == 2) q.solve_ferrari(inv_dd, T.Rb2);   // wave-uniform: the scene's solver
@@ -525,13 +602,11 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
   }
   else
   {
-    // The first trip is peeled: right after setup() every field the transitions read is a known
-    // constant (mode END at xe = A = B = lo, sigma = sref = 1, it = 0, B < hi), so the compiler folds
-    // step() into "enter the first piece from lo" — a third of the general trip — and the first
-    // evaluation is about half of all evaluations (2.1 per solved test on the baseline frame).
+#ifdef TRT_WALK_TABLE
+    // the resumable state machine of the persistent kernel, first trip peeled (right after setup()
+    // every field the transitions read is a known constant, so the compiler folds step())
     ++wc.evals;
     bool run = q.step();
-    // per trip: the cheap iteration-only step when every running lane of the wave is iterating
     while(run)
     {
       ++wc.evals;
@@ -540,6 +615,9 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
       else
         run = q.step_iter();
     }
+#else
+    q.walk(wc.evals);
+#endif
   }
   return q.finish(dx_, dy_, dz_, tmin, tmax, T, t_out);
 }
