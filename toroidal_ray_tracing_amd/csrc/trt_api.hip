@@ -559,8 +559,10 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     a.tiles_clear = a.tiles_live + n_tiles;
     a.cap_live    = (uint32_t)n_tiles;
     a.cap_clear   = (uint32_t)n_tiles;
-    // tile culling needs tiles that are 8 contiguous image rows, and no per-pixel ray export
-    a.tile_cull = (rendered == nullptr && (a.tile_parts <= 1 || a.tile_group % 8 == 0)) ? 1u : 0u;
+    // tile culling needs tiles that are 8 contiguous image rows; with a RenderedData export the listed
+    // kernel still writes the primary ray and the miss record of every pixel of a culled tile (raygen
+    // only, no solve), the persistent kernel does not: it then traces every tile
+    a.tile_cull = ((rendered == nullptr || ctx->variant == kRenderListed) && (a.tile_parts <= 1 || a.tile_group % 8 == 0)) ? 1u : 0u;
     a.min_batch = ctx->tn.min_batch;
     if(ctx->tn.no_tile_cull) a.tile_cull = 0;
     // The finer, per-tile classification costs 8 µs more at 4096² and pays when most macro tiles

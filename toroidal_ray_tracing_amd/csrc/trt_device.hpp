@@ -774,7 +774,10 @@ __device__ __forceinline__ void raygen(const trt_globals& g, const ToroCam& tc, 
 {
   if(camera == TRT_CAMERA_TOROIDAL)
   {
-    const float ca = tc.cos_a[x], sa = tc.sin_a[x], cb = tc.cos_b[y], sb = tc.sin_b[y];
+    // the table pointers come out of the LDS-staged arguments: tell hipcc they address global memory
+    // (global_load instead of flat_load, which would also count on lgkmcnt)
+    typedef __attribute__((address_space(1))) const float* gcf;
+    const float ca = ((gcf)tc.cos_a)[x], sa = ((gcf)tc.sin_a)[x], cb = ((gcf)tc.cos_b)[y], sb = ((gcf)tc.sin_b)[y];
     origin = {fma_(tc.rho, ca, tc.eye[0]), tc.eye[1], fma_(tc.rho, sa, tc.eye[2])};  // BEF rgen:56
     dir    = {ca * cb, sb, sa * cb};                                                // BEF rgen:57
     return;

@@ -235,18 +235,82 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
 // ------------------------------------------------------------------------------------------
 // One pixel, start to finish, on one lane: the reference's raygen main() with the closest-hit,
 // miss and shadow-miss shaders inlined (REFL/shaders/raytrace.rgen:40-88).
+// ------------------------------------------------------------------------------------------
+// RenderedData export (BEF/shaders/raytrace.rgen:72-73,111-112), staged through LDS
+// ------------------------------------------------------------------------------------------
+// RenderedData is an array of 64-B records at index x*H + y: the 8 pixels of one tile COLUMN are
+// 512 contiguous bytes, but a lane that stores its own record piece by piece (rayOrigin/rayDir at
+// ray generation, pos at the first hit, colour at the end) writes 16 B of every 64 — a wave
+// instruction then touches 32 cache lines for 1 KB, and the four pieces of a record reach the L2
+// far apart in time.  The listed kernel therefore collects the 64 records of its 8×8 tile in a
+// per-wave LDS image (4 KB) and writes it out transposed: 4 dwordx4 instructions, each covering two
+// whole tile columns = 2 × 512 contiguous bytes (8 full lines per instruction, like every other
+// store of the frame).  Record of tile pixel (x, y), piece k (0 pos, 1 colour, 2 rayOrigin,
+// 3 rayDir) sits at 16-B unit y·32 + ((x ^ y) & 7)·4 + k: the XOR spreads a column over the banks,
+// so neither the record writes (lanes of equal y) nor the column reads (lanes of equal x) conflict.
+__device__ __forceinline__ uint32_t rd_unit(uint32_t x, uint32_t y, uint32_t k) { return y * 32u + (((x ^ y) & 7u) << 2) + k; }
+
+// Where a lane puts the pieces of its pixel's record: the wave's LDS image (listed kernel), or — the
+// other variants — straight to global memory.
+struct RdSink {
+  float4* lds;   // the wave's 256-unit image, already offset to this lane's record (or nullptr)
+  float*  glob;  // &rendered[x*H + y] (or nullptr)
+  __device__ __forceinline__ explicit operator bool() const { return lds != nullptr || glob != nullptr; }
+  __device__ __forceinline__ void put(uint32_t k, float4 v) const
+  {
+    if(lds) lds[k] = v;
+    else if(glob) st4(glob + 4 * k, v);
+  }
+};
+
+// Writes the wave's LDS image of tile (tx, ty) to RenderedData, transposed (see above).
+__device__ __forceinline__ void rd_flush(const RenderArgs& a, const float4* tile, uint32_t tx, uint32_t ty, uint32_t lane)
+{
+  __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the reads below see the records
+#pragma unroll
+  for(uint32_t j = 0; j < 4; ++j)
+  {
+    const uint32_t c = j * 64u + lane, xl = c >> 5, yl = (c >> 2) & 7u, k = c & 3u;
+    const uint32_t x = tx * 8u + xl, ly = ty * 8u + yl;
+    if(x < a.W && ly < a.n_local_rows)
+    {
+      const float4 v = tile[rd_unit(xl, yl, k)];
+      st4(reinterpret_cast<float*>(&a.rendered[(size_t)x * a.H + image_row(a, ly)]) + 4 * k, v);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The record of a pixel that misses at depth 0, for a whole tile that the classification proved
+// empty: primary ray from raygen(), pos = (0,0,0,1) (BEF rmiss:21 → rgen:112), colour = clear·0.8
+// (rmiss:37 → rgen:76 with attenuation 1 → rgen:111) — what trace_pixel() would have produced.
+__device__ __forceinline__ void rd_miss_tile(const RenderArgs& a, float4* tile, uint32_t tx, uint32_t ty, uint32_t lane)
+{
+  const uint32_t xl = lane & 7u, yl = lane >> 3, x = tx * 8u + xl, ly = ty * 8u + yl;
+  if(x < a.W && ly < a.n_local_rows)
+  {
+    v3 o, d;
+    raygen(a.g, a.toro, a.W, a.H, a.camera, x, image_row(a, ly), o, d);
+    float4* r = tile + rd_unit(xl, yl, 0);
+    r[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    r[1] = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, 1.0f);
+    r[2] = make_float4(o.x, o.y, o.z, 1.0f);
+    r[3] = make_float4(d.x, d.y, d.z, 0.0f);
+  }
+  rd_flush(a, tile, tx, ty, lane);
+}
+
 template <class Real, bool DK>
-__device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a, uint32_t x, uint32_t y, uint32_t ly,
+__device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a, uint32_t x, uint32_t y, uint32_t ly, const RdSink rd,
                                             uint32_t& n_primary, uint32_t& n_bounce, uint32_t& n_shadow, WorkCount& wc)
 {
   const size_t oi = out_index(a, x, y, ly);
   v3 origin, direction;
   raygen(a.g, a.toro, a.W, a.H, a.camera, x, y, origin, direction);
-  float* rd = a.rendered ? reinterpret_cast<float*>(&a.rendered[(size_t)x * a.H + y]) : nullptr;  // BEF rgen:72
   if(rd)
   {
-    st4(rd + 8, make_float4(origin.x, origin.y, origin.z, 1.0f));            // BEF rgen:56,72
-    st4(rd + 12, make_float4(direction.x, direction.y, direction.z, 0.0f));  // BEF rgen:57,73
+    rd.put(2, make_float4(origin.x, origin.y, origin.z, 1.0f));            // BEF rgen:56,72
+    rd.put(3, make_float4(direction.x, direction.y, direction.z, 0.0f));   // BEF rgen:57,73
   }
 
   int depth = 0, done = 1;                                                 // rgen:54,57
@@ -268,7 +332,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
           // materialised here: hoisted out of the tile loop this constant vector gets spilled
           float z, o1;
           asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 1.0" : "=v"(z), "=v"(o1));
-          st4(rd, make_float4(z, z, z, o1));
+          rd.put(0, make_float4(z, z, z, o1));
         }
       }
     }
@@ -279,7 +343,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
       if(depth == 0)                                                       // BEF rgen:94-97
       {
         store_first_hit(a, oi, t, h.P, h.N, id);
-        if(rd) st4(rd, make_float4(h.P.x, h.P.y, h.P.z, 1.0f));            // BEF rgen:112
+        if(rd) rd.put(0, make_float4(h.P.x, h.P.y, h.P.z, 1.0f));          // BEF rgen:112
       }
       bool shadowed = false;
       if(h.wantShadow)
@@ -298,7 +362,7 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
   }
   const float4 c = make_float4(hitValue.x, hitValue.y, hitValue.z, 1.0f);
   if(a.rgba) st4(a.rgba + 4 * oi, c);                                      // rgen:87
-  if(rd) st4(rd + 4, c);                                                   // BEF rgen:111
+  if(rd) rd.put(1, c);                                                     // BEF rgen:111
 }
 
 template <class Real, int TW, bool DK>
@@ -318,7 +382,11 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
   WorkCount wc;
   if(x < a.W && ly < a.n_local_rows)
-    trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow, wc);
+  {
+    const uint32_t y = image_row(a, ly);
+    const RdSink rd{nullptr, a.rendered ? reinterpret_cast<float*>(&a.rendered[(size_t)x * a.H + y]) : nullptr};   // BEF rgen:72
+    trace_pixel<Real, DK>(S, a, x, y, ly, rd, n_primary, n_bounce, n_shadow, wc);
+  }
   if(a.stats)
   {
     block_add_stats(a.stats, n_primary, n_bounce, n_shadow, wc);
@@ -1008,11 +1076,14 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 #endif
 // Waves per SIMD the register allocation aims at.  The counted (STATS) instantiations carry six
 // counters per lane and run only in the untimed counted pass: they get one wave less instead of scratch.
-template <class Real, bool STATS, bool DK>
-__global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64) - (STATS ? 1 : 0))) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
+// RD: the launch exports RenderedData (a.rendered != nullptr); every wave then owns a 4-KB LDS image.
+template <class Real, bool STATS, bool DK, bool RD>
+__global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64) - ((STATS || RD) ? 1 : 0))) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
 {
   __shared__ SceneK     S;
   __shared__ RenderArgs A_lds;
+  __shared__ float4     rd_images[RD ? 4 : 1][RD ? 256 : 1];
+  float4* const rd_tile = RD ? rd_images[threadIdx.x >> 6] : nullptr;
   stage_args(&A_lds, a_arg);
   stage_scene(&S, scene);
   const RenderArgs& a = A_lds;
@@ -1050,11 +1121,19 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
     if(i < my_clear && !TRT_SKIP(a, 1u) && !TRT_SKIP(a, 4u))
-      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), ln) * (uint32_t)S.n_tori;
+    {
+      const uint32_t cpacked = __builtin_amdgcn_readlane(clear_cache, i & 63u);
+      n_primary += clear_macro(a, cpacked, ln) * (uint32_t)S.n_tori;
+      if(RD)   // the four 8×8 tiles of the macro tile: primary rays + miss record, no solve
+        for(uint32_t j = 0; j < kMacroTiles; ++j)
+          rd_miss_tile(a, rd_tile, tile_x(cpacked) + j, tile_y(cpacked), ln);
+    }
     if(i < my_live && !TRT_SKIP(a, 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
       const uint32_t x = tile_x(packed) * 8 + (ln & 7), ly = tile_y(packed) * 8 + (ln >> 3);
+      if(RD && (packed & kTileMissFlag))
+        rd_miss_tile(a, rd_tile, tile_x(packed), tile_y(packed), ln);
       if(x < a.W && ly < a.n_local_rows)
       {
         if(packed & kTileMissFlag)
@@ -1068,8 +1147,11 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
           n_primary += (uint32_t)S.n_tori;
         }
         else
-          trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, n_primary, n_bounce, n_shadow, wc);
+          trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, RdSink{RD ? rd_tile + rd_unit(ln & 7, ln >> 3, 0) : nullptr, nullptr},
+                                n_primary, n_bounce, n_shadow, wc);
       }
+      if(RD && !(packed & kTileMissFlag))
+        rd_flush(a, rd_tile, tile_x(packed), tile_y(packed), ln);
     }
   }
 #ifdef TRT_TUNING
@@ -1324,8 +1406,10 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
 #define TRT_LAUNCH_LISTED(REAL, DK_)                                                                                   \
   do {                                                                                                                 \
-    if(a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, DK_>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);  \
-    else hipLaunchKernelGGL((render_listed_kernel<REAL, false, DK_>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);        \
+    if(a.rendered && a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, DK_, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);  \
+    else if(a.rendered) hipLaunchKernelGGL((render_listed_kernel<REAL, false, DK_, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);       \
+    else if(a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, DK_, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);          \
+    else hipLaunchKernelGGL((render_listed_kernel<REAL, false, DK_, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);                     \
   } while(0)
       if(scene.f64 && scene.dk) TRT_LAUNCH_LISTED(double, true);
       else if(scene.f64) TRT_LAUNCH_LISTED(double, false);
