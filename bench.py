@@ -164,7 +164,7 @@ def cpu_baseline(sc, g, pc, W, H):
            "solved_tests_per_s": frames * int(st.solved_tests) / t}
     # one thread: a band of rows through the image centre (where the torus is: the expensive rows)
     # and the same number of rows from the top (all misses), weighted to the whole frame
-    band = max(8, min(H // 2, 64))
+    band = max(8, min(H // 2, 512))
     t_mid, st_mid = run(g, pc, W, H, H // 2 - band // 2, H // 2 + band // 2, 1)
     t_top, _ = run(g, pc, W, H, 0, band, 1)
     out["one_thread"] = {"cores": 1, "sample": f"rows {H // 2 - band // 2}..{H // 2 + band // 2} (through the torus) and 0..{band} (all misses) "
@@ -291,6 +291,26 @@ def secondary(tr, dev, stream):
     pcc.rho = 4.0
     render_case("toroidal capture 4096x2048 with RenderedData (BEF)", camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC),
                 camera.toroidal_camera(Wc, Hc), pcc, cam=1, Wr=Wc, Hr=Hc, rendered=rend, bpp=BYTES_PER_PIXEL_CAPTURE)
+    del rend
+    # the consumer of the capture: point-cloud re-projection (SEC), 8.4 M random points -> 2048² (32 B/point + 24 B/pixel:
+    # 8-B key + 16-B colour per pixel), and the tonemap of a 4096² frame -> rgba8 (16 B in + 4 B out)
+    n = 4096 * 2048
+    gen = torch.Generator(device=dev).manual_seed(2)
+    cloud = torch.zeros(n, 8, device=dev)
+    cloud[:, :3] = torch.rand(n, 3, device=dev, generator=gen) * 6 - 3
+    cloud[:, 4:7] = torch.rand(n, 3, device=dev, generator=gen)
+    vp = camera.perspective_vk(60, 1.0) @ camera.look_at((1.0, 2.0, 7.0), (0.0, 0.0, 0.0))
+    img2 = torch.empty(2048, 2048, 4, device=dev)
+    ms = timeit(lambda: tr.splat_dev(cloud.data_ptr(), n, vp, 2048, 2048, img2.data_ptr(), stream=s), reps=5)
+    by = 32 * n + 24 * 2048 * 2048
+    res.append({"name": "re-projection (SEC), 8.4 M random points -> 2048^2", "ms": ms, "units": n, "GB_per_s": by / ms / 1e6,
+                "frac_hbm": by / ms / 1e6 / HBM_PEAK_GBPS, "dtype": "u64 keys", "bound": "hbm", "kernel": "splat_count/scan/scatter/resolve_bins",
+                "points_per_s": n / ms * 1e3})
+    del cloud, img2
+    o8 = torch.empty(W, W, 4, dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: tr.post_dev(rgba.data_ptr(), W * W, 0, o8.data_ptr(), stream=s))
+    res.append({"name": "post pass (post.frag tonemap), 4096^2 -> rgba8", "ms": ms, "units": W * W, "GB_per_s": 20 * W * W / ms / 1e6,
+                "frac_hbm": 20 * W * W / ms / 1e6 / HBM_PEAK_GBPS, "dtype": "f32", "bound": "hbm", "kernel": "post_kernel"})
     return res
 
 

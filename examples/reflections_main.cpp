@@ -35,7 +35,16 @@ int main(int argc, char** argv)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%ux%u, maxDepth %d: %d frames in %.2f ms (%.3f ms/frame incl. readback of the last)\n", W, H, depth,
                 frames, ms, ms / frames);
-    if(outdir) helloVk.writeColorImage(outdir);  // main.cpp:326-330
+    if(outdir)
+    {
+      helloVk.writeColorImage(outdir);  // main.cpp:326-330
+      // the ground-truth dump of ray_tracing_reflections/hello_vulkan.cpp:1065-1110 ("data/<scene>gTruth.txt") and
+      // the presented image (post.frag) as a PPM
+      helloVk.writeColorImageAs(std::string(outdir) + "data/torusgTruth.txt");
+      helloVk.drawPost(nullptr);
+      helloVk.copyPostImage(nullptr);
+      helloVk.writePostImagePPM(std::string(outdir) + "data/torusgTruth.ppm");
+    }
     const float* px = &helloVk.colorImage()[((size_t)(H / 2) * W + W / 2) * 4];
     std::printf("centre pixel = %g %g %g %g\n", px[0], px[1], px[2], px[3]);
   }

@@ -1,6 +1,8 @@
 // reproject_main.cpp — ray_tracing__before_second/main.cpp without the window: load a capture
 // (renderedPosition<rho>.txt + renderedColor<rho>.txt as written by toroidal_sweep), rasterise it
-// as a point cloud from a pinhole viewpoint, tonemap, dump the image as text (writeColorImage).
+// as a point cloud from a pinhole viewpoint, tonemap, dump the image as text — the reference's
+// data/<scene>ptCloudImage_10.txt (ray_tracing__before_second/hello_vulkan.cpp:781-825: "r g b" per
+// pixel, row-major) — and as a PPM of the presented 8-bit image.
 // Usage: reproject dir/ rho [width height]      e.g.  reproject /tmp/cap/ 4.500000 512 512
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +30,8 @@ int main(int argc, char** argv)
     helloVk.drawPost(nullptr);
     helloVk.copyColorImage(nullptr);
     helloVk.copyPostImage(nullptr);
+    helloVk.writeColorImageAs(dir + "data/torusptCloudImage_10.txt");   // SEC writeColorImage (:797-806 naming)
+    helloVk.writePostImagePPM(dir + "data/torusptCloudImage_10.ppm");
     size_t drawn = 0;
     for(size_t i = 0; i < (size_t)W * H; ++i)
       drawn += helloVk.colorImage()[4 * i] != 0.8f || helloVk.colorImage()[4 * i + 1] != 0.8f;

@@ -14,7 +14,7 @@
  *   raygen binding contract        REFL/shaders/raytrace.rgen:30-35,
  *                                  BEF/shaders/raytrace.rgen:10-17       trt_globals/trt_push/outputs
  *   traceRayEXT closest/any hit    REFL/shaders/raytrace.rgen:64-75,
- *                                  REFL/shaders/raytrace.rchit:208-219   trt_trace*
+ *                                  REFL/shaders/raytrace.rchit:120-131   trt_trace*
  *   TLAS + ObjDesc + materials     REFL/hello_vulkan.cpp:645-683,264-273 trt_scene
  *   RenderedData SSBO              BEF/shaders/host_device.h:101-107     trt_rendered_data
  *

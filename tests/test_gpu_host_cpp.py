@@ -37,6 +37,16 @@ def test_reflections_example_matches_oracle(tmp_path, oracle):
     # flip, everything else agrees to the 6 significant digits the text format keeps
     close = np.isclose(got, want, rtol=2e-4, atol=2e-5).all(axis=1)
     assert close.mean() > 0.995
+    # the ground-truth dump (REFL/hello_vulkan.cpp:1065-1110 naming) is the same text, and the PPM holds the
+    # tonemapped bytes of the post pass (post.frag): P6 header + W*H RGB triples == oracle.post of the frame
+    assert (tmp_path / "data" / "torusgTruth.txt").read_text() == (tmp_path / "data" / "renderedColor0.000000.txt").read_text()
+    raw = (tmp_path / "data" / "torusgTruth.ppm").read_bytes()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    ppm = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+    rgba = np.concatenate([got.reshape(H, W, 3), np.ones((H, W, 1))], axis=2).astype(np.float32)
+    _, w8 = oracle.post(rgba)          # from the 6-digit text: bytes may differ by one count at rounding boundaries
+    assert np.abs(ppm.astype(int) - w8[..., :3].astype(int)).max() <= 1 and (ppm == w8[..., :3]).mean() > 0.99
 
 
 def test_toroidal_sweep_formats(tmp_path):
@@ -86,3 +96,8 @@ def test_reproject_example_consumes_a_capture(tmp_path):
                          text=True).stdout
     n_points, covered = int(out.split()[0]), int(out.split("pixels covered")[0].split(",")[-1])
     assert n_points == W * H and 0 < covered < 128 * 96
+    # the re-projected image as the reference dumps it (SEC/hello_vulkan.cpp:781-825): one "r g b" line per pixel
+    img = _load(tmp_path / "data" / "torusptCloudImage_10.txt")
+    assert img.shape == (128 * 96, 3) and abs(int((img[:, :2] != 0.8).any(axis=1).sum()) - covered) <= 2   # 6-digit text
+    raw = (tmp_path / "data" / "torusptCloudImage_10.ppm").read_bytes()
+    assert raw.startswith(b"P6\n128 96\n255\n") and len(raw) == len(b"P6\n128 96\n255\n") + 128 * 96 * 3

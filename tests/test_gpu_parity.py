@@ -904,6 +904,21 @@ def test_splat_bit_exact(tr, oracle):
         torch.cuda.synchronize()
         want = oracle.splat(pts, vp, W, H)
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # point sizes that straddle several 128x64 bins (binned form: <= 32 pixels) and one beyond it (one-pass form),
+    # on an image of 3 x 4 bins with a ragged edge; repeated calls reuse the bin counters
+    W, H, n = 300, 200, 40_000
+    pts = np.zeros((n, 8), np.float32)
+    pts[:, :3] = rng.uniform(-3, 3, (n, 3))
+    pts[:, 4:7] = rng.uniform(0, 1, (n, 3))
+    pts[n // 3:n // 3 + 500] = pts[:500]                               # depth ties across bins
+    vp = camera.perspective_vk(70, W / H) @ camera.look_at((0.5, 1.0, 5.0), (0, 0, 0))
+    d_pts = torch.from_numpy(pts).to(dev)
+    out = torch.empty(H, W, 4, device=dev)
+    for size in (1.0, 2.5, 9.0, 31.5, 40.0, 2.5):
+        tr.splat_dev(d_pts.data_ptr(), n, vp, W, H, out.data_ptr(), point_size=size, stream=s)
+        torch.cuda.synchronize()
+        want = oracle.splat(pts, vp, W, H, point_size=size)
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=f"point_size {size}")
     # no points at all: the clear colour everywhere
     tr.splat_dev(0, 0, vp, W, H, out.data_ptr(), clear=(0.1, 0.2, 0.3, 1.0), stream=s)
     torch.cuda.synchronize()

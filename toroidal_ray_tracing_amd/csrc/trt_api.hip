@@ -58,7 +58,9 @@ struct trt_ctx {
   // staging for the host-pointer entry points (grow-only, freed in trt_destroy)
   DevBuf d_in[6], d_out[8], d_rgba, d_rendered;
   DevBuf d_tiles;  // LIVE + CLEAR tile lists of the persistent kernel
-  DevBuf d_keys;   // depth|index keys of trt_splat_dev
+  DevBuf d_keys;   // depth|index keys of trt_splat_dev (one-pass form)
+  DevBuf d_bins;   // … binned form: per-bin count / offset / cursor words (count zero between calls)
+  DevBuf d_recs;   // … binned form: point records sorted by bin
 };
 
 namespace {
@@ -97,6 +99,8 @@ bool capturing(hipStream_t st)
 // Grow-only scratch.  Growing frees the old block: a hipGraph captured earlier still holds the old
 // address (include/trt.h: size the ctx with an eager call first), and hipFree/hipMalloc are illegal
 // while `st` is being captured — then the call is refused instead.
+constexpr size_t kSplatBinWordsAlloc = 8192;   // = kSplatMaxBins of trt_kernels.hip
+
 int grow(trt_ctx* ctx, DevBuf& b, size_t bytes, hipStream_t st = nullptr)
 {
   if(bytes <= b.cap) return TRT_OK;
@@ -322,7 +326,7 @@ extern "C" void trt_destroy(trt_ctx* ctx)
   if(ctx->d_stats) (void)hipFree(ctx->d_stats);
   if(ctx->d_queue) (void)hipFree(ctx->d_queue);
   if(ctx->h_toro) (void)hipHostFree(ctx->h_toro);
-  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered, &ctx->d_tiles, &ctx->d_keys};
+  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered, &ctx->d_tiles, &ctx->d_keys, &ctx->d_bins, &ctx->d_recs};
   for(DevBuf* b : all)
     if(b->p) (void)hipFree(b->p);
   for(DevBuf& b : ctx->d_in)
@@ -704,8 +708,29 @@ extern "C" int trt_splat_dev(trt_ctx* ctx, const trt_point* points, uint64_t n_p
   if(((uintptr_t)points | (uintptr_t)rgba) & 15)
     return fail(ctx, TRT_E_INVALID, "trt_splat: the point buffer and the rgba image must be 16-byte aligned (float4 accesses)");
   TRT_HIP(ctx, hipSetDevice(ctx->device));
-  if(int rc = grow(ctx, ctx->d_keys, (size_t)W * H * sizeof(unsigned long long), (hipStream_t)stream)) return rc;
-  TRT_HIP(ctx, launch_splat(points, n_points, viewProj, W, H, clearColor, point_size,
-                            (unsigned long long*)ctx->d_keys.p, rgba, ctx->n_cus, ctx->tn, (hipStream_t)stream));
+  hipStream_t  st = (hipStream_t)stream;
+  SplatScratch sc{};
+  sc.n_bins = splat_bins(W, H, point_size, n_points, ctx->tn);
+  if(sc.n_bins)
+  {
+    const size_t words = 3 * (size_t)kSplatBinWordsAlloc;   // sized for the largest bin count once: the counts must stay zero between calls
+    if(ctx->d_bins.cap < words * sizeof(uint32_t))
+    {
+      if(int rc = grow(ctx, ctx->d_bins, words * sizeof(uint32_t), st)) return rc;
+      TRT_HIP(ctx, hipMemsetAsync(ctx->d_bins.p, 0, words * sizeof(uint32_t), st));   // never inside a capture: grow() refuses there
+    }
+    // records (4 per point at most: a point of <= 32 pixels touches <= 2 x 2 bins) followed by the projected points
+    const size_t np = n_points ? (size_t)n_points : 1;
+    if(int rc = grow(ctx, ctx->d_recs, np * (4 * 16 + 8), st)) return rc;
+    sc.bin_words = (uint32_t*)ctx->d_bins.p;
+    sc.records   = ctx->d_recs.p;
+    sc.proj      = (char*)ctx->d_recs.p + np * 4 * 16;
+  }
+  else
+  {
+    if(int rc = grow(ctx, ctx->d_keys, (size_t)W * H * sizeof(unsigned long long), st)) return rc;
+    sc.keys = (unsigned long long*)ctx->d_keys.p;
+  }
+  TRT_HIP(ctx, launch_splat(points, n_points, viewProj, W, H, clearColor, point_size, sc, rgba, ctx->n_cus, ctx->tn, st));
   return TRT_OK;
 }

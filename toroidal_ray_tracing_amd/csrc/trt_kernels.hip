@@ -1251,31 +1251,228 @@ struct SplatArgs {
   float    half;   // point_size / 2
 };
 
+// Vertex stage + point rasterisation set-up of one point: false when the vertex is clipped or the point
+// covers no pixel centre; else its 24-bit depth and the pixel rectangle [x0,x1) × [y0,y1) it covers.
+__device__ __forceinline__ bool splat_project(float4 p, const SplatArgs& a, uint32_t& z24, int& x0, int& x1, int& y0, int& y1)
+{
+  // gl_Position = uni.viewProj * vec4(position, 1.0)   (SEC vert_shader.vert:51)
+  const float cx = fma_(a.vp[12], 1.0f, fma_(a.vp[8], p.z, fma_(a.vp[4], p.y, a.vp[0] * p.x)));
+  const float cy = fma_(a.vp[13], 1.0f, fma_(a.vp[9], p.z, fma_(a.vp[5], p.y, a.vp[1] * p.x)));
+  const float cz = fma_(a.vp[14], 1.0f, fma_(a.vp[10], p.z, fma_(a.vp[6], p.y, a.vp[2] * p.x)));
+  const float cw = fma_(a.vp[15], 1.0f, fma_(a.vp[11], p.z, fma_(a.vp[7], p.y, a.vp[3] * p.x)));
+  if(!(cw > 0.0f && cx >= -cw && cx <= cw && cy >= -cw && cy <= cw && cz >= 0.0f && cz <= cw))
+    return false;  // point clipping: the vertex is outside the view volume (NaN lands here too)
+  const float iw = 1.0f / cw;
+  const float xf = fma_(cx * iw, 0.5f, 0.5f) * (float)a.W;
+  const float yf = fma_(cy * iw, 0.5f, 0.5f) * (float)a.H;
+  z24 = (uint32_t)rintf((cz * iw) * 16777215.0f);
+  // pixel centres c = j + 0.5 with lo <= c < hi  ⇔  j in [ceil(lo - 0.5), ceil(hi - 0.5))
+  x0 = max((int)ceilf(xf - a.half - 0.5f), 0); x1 = min((int)ceilf(xf + a.half - 0.5f), (int)a.W);
+  y0 = max((int)ceilf(yf - a.half - 0.5f), 0); y1 = min((int)ceilf(yf + a.half - 0.5f), (int)a.H);
+  return x0 < x1 && y0 < y1;
+}
+
 __global__ __launch_bounds__(256) void splat_points_kernel(const trt_point* __restrict__ pts, uint64_t n, const SplatArgs a,
                                                            unsigned long long* keys)
 {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
   {
-    const float4 p = reinterpret_cast<const float4*>(pts)[2 * i];
-    // gl_Position = uni.viewProj * vec4(position, 1.0)   (SEC vert_shader.vert:51)
-    const float cx = fma_(a.vp[12], 1.0f, fma_(a.vp[8], p.z, fma_(a.vp[4], p.y, a.vp[0] * p.x)));
-    const float cy = fma_(a.vp[13], 1.0f, fma_(a.vp[9], p.z, fma_(a.vp[5], p.y, a.vp[1] * p.x)));
-    const float cz = fma_(a.vp[14], 1.0f, fma_(a.vp[10], p.z, fma_(a.vp[6], p.y, a.vp[2] * p.x)));
-    const float cw = fma_(a.vp[15], 1.0f, fma_(a.vp[11], p.z, fma_(a.vp[7], p.y, a.vp[3] * p.x)));
-    if(!(cw > 0.0f && cx >= -cw && cx <= cw && cy >= -cw && cy <= cw && cz >= 0.0f && cz <= cw))
-      continue;  // point clipping: the vertex is outside the view volume (NaN lands here too)
-    const float iw = 1.0f / cw;
-    const float xf = fma_(cx * iw, 0.5f, 0.5f) * (float)a.W;
-    const float yf = fma_(cy * iw, 0.5f, 0.5f) * (float)a.H;
-    const uint32_t z24 = (uint32_t)rintf((cz * iw) * 16777215.0f);
+    uint32_t z24;
+    int x0, x1, y0, y1;
+    if(!splat_project(reinterpret_cast<const float4*>(pts)[2 * i], a, z24, x0, x1, y0, y1))
+      continue;
     const unsigned long long key = ((unsigned long long)z24 << 32) | (unsigned long long)(uint32_t)i;
-    // pixel centres c = j + 0.5 with lo <= c < hi  ⇔  j in [ceil(lo - 0.5), ceil(hi - 0.5))
-    const int x0 = max((int)ceilf(xf - a.half - 0.5f), 0), x1 = min((int)ceilf(xf + a.half - 0.5f), (int)a.W);
-    const int y0 = max((int)ceilf(yf - a.half - 0.5f), 0), y1 = min((int)ceilf(yf + a.half - 0.5f), (int)a.H);
     for(int y = y0; y < y1; ++y)
       for(int x = x0; x < x1; ++x)
         atomicMin(&keys[(size_t)y * a.W + x], key);
+  }
+}
+
+// ---- binned re-projection: the depth test in LDS -------------------------------------------------
+// The one-pass form above sends ≈6 64-bit atomicMin per point to the memory side (≈26 G atomics/s chip-wide:
+// 2 ms for 8.4 M random points).  Here the screen is cut into bins of 128 × 64 pixels — 8,192 keys = 64 KB, one
+// LDS image — and the points are first sorted by bin:
+//   count    every block projects its chunk of points ONCE — the 8-B result {depth24, pixel rectangle} goes to a
+//            side array — and histograms it over the bins in LDS, one global add per non-empty bin;
+//   scan     exclusive prefix of the bin counts (one block);
+//   scatter  the same chunks again, from the side array (two sweeps, L2-resident): a block reserves one range
+//            per bin (one global add), its points take their ranks from an LDS counter and write 16-B records
+//            {point index, depth24, rectangle inside the bin};
+//   resolve  ONE block per bin: atomicMin of the keys in LDS (ds_min_u64), then every pixel of the bin is written
+//            once — colour of the winning point, or the clear colour.
+// The keys, and so the image, are those of the one-pass form bit for bit (a minimum does not depend on the
+// order of its operands).  A point wider than a bin edge would need more than 4 records: such sizes, and images
+// with more than kSplatMaxBins bins, take the one-pass form.
+constexpr uint32_t kBinW = 128, kBinH = 64, kSplatMaxBins = 8192, kSplatChunk = 8192, kSplatMaxDim = 16383;
+
+struct SplatBins {
+  uint32_t  bins_x, bins_y, n_bins;
+  uint32_t* count;    // [n_bins]   points per bin: accumulated by `count`, zeroed again by `resolve`
+  uint32_t* offset;   // [n_bins]   first record of the bin (scan)
+  uint32_t* cursor;   // [n_bins]   records handed out so far (zeroed by scan)
+  uint4*    records;  // [<= 4 · n_points]
+  uint2*    proj;     // [n_points] the projected points (count → scatter)
+};
+
+// projected point in 64 bits: x0 (14) | y0 (14) | width low 4 bits ; depth24 | width high 2 bits | height (6).
+// W, H <= 16383 and point_size <= 32 (width, height <= 33) on this path; width 0 = the point draws nothing.
+__device__ __forceinline__ uint2 splat_pack(uint32_t z24, int x0, int x1, int y0, int y1)
+{
+  const uint32_t w = (uint32_t)(x1 - x0), h = (uint32_t)(y1 - y0);
+  return make_uint2((uint32_t)x0 | ((uint32_t)y0 << 14) | ((w & 15u) << 28), z24 | ((w >> 4) << 24) | (h << 26));
+}
+__device__ __forceinline__ bool splat_unpack(uint2 p, uint32_t& z24, int& x0, int& x1, int& y0, int& y1)
+{
+  const uint32_t w = (p.x >> 28) | (((p.y >> 24) & 3u) << 4), h = p.y >> 26;
+  x0 = (int)(p.x & 16383u); y0 = (int)((p.x >> 14) & 16383u); x1 = x0 + (int)w; y1 = y0 + (int)h;
+  z24 = p.y & 0xffffffu;
+  return w != 0u;
+}
+
+// calls f(bin, x0r, x1r, y0r, y1r) for every bin the rectangle touches, rectangle clipped to the bin, bin-relative
+template <class F>
+__device__ __forceinline__ void splat_for_bins(const SplatBins& b, int x0, int x1, int y0, int y1, F f)
+{
+  const int bx0 = x0 / (int)kBinW, bx1 = (x1 - 1) / (int)kBinW, by0 = y0 / (int)kBinH, by1 = (y1 - 1) / (int)kBinH;
+  for(int by = by0; by <= by1; ++by)
+    for(int bx = bx0; bx <= bx1; ++bx)
+    {
+      const int ox = bx * (int)kBinW, oy = by * (int)kBinH;
+      f((uint32_t)by * b.bins_x + (uint32_t)bx, max(x0 - ox, 0), min(x1 - ox, (int)kBinW), max(y0 - oy, 0), min(y1 - oy, (int)kBinH));
+    }
+}
+
+__global__ __launch_bounds__(256) void splat_count_kernel(const trt_point* __restrict__ pts, uint64_t n, const SplatArgs a, const SplatBins b)
+{
+  extern __shared__ uint32_t hist[];
+  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x) hist[k] = 0u;
+  __syncthreads();
+  const uint64_t i0 = (uint64_t)blockIdx.x * kSplatChunk, i1 = min(n, i0 + kSplatChunk);
+  for(uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+  {
+    uint32_t z24;
+    int x0, x1, y0, y1;
+    uint2 pk = make_uint2(0u, 0u);
+    if(splat_project(reinterpret_cast<const float4*>(pts)[2 * i], a, z24, x0, x1, y0, y1))
+    {
+      pk = splat_pack(z24, x0, x1, y0, y1);
+      splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int, int, int, int) { atomicAdd(&hist[bin], 1u); });
+    }
+    b.proj[i] = pk;
+  }
+  __syncthreads();
+  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x)
+    if(hist[k]) atomicAdd(&b.count[k], hist[k]);
+}
+
+__global__ __launch_bounds__(1024) void splat_scan_kernel(const SplatBins b)
+{
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (b.n_bins + 1023u) / 1024u, k0 = threadIdx.x * per, k1 = min(b.n_bins, k0 + per);
+  uint32_t sum = 0;
+  for(uint32_t k = k0; k < k1; ++k) sum += b.count[k];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    uint32_t run = 0;
+    for(uint32_t t = 0; t < 1024u; ++t) { const uint32_t c = part[t]; part[t] = run; run += c; }
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for(uint32_t k = k0; k < k1; ++k)
+  {
+    b.offset[k] = run;
+    b.cursor[k] = 0u;
+    run += b.count[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void splat_scatter_kernel(uint64_t n, const SplatBins b)
+{
+  extern __shared__ uint32_t lds[];
+  uint32_t* hist = lds;             // [n_bins] points of this block per bin, then the rank counter
+  uint32_t* base = lds + b.n_bins;  // [n_bins] first record of this block's range in the bin
+  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x) hist[k] = 0u;
+  __syncthreads();
+  const uint64_t i0 = (uint64_t)blockIdx.x * kSplatChunk, i1 = min(n, i0 + kSplatChunk);
+  for(uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+  {
+    uint32_t z24;
+    int x0, x1, y0, y1;
+    if(splat_unpack(b.proj[i], z24, x0, x1, y0, y1))
+      splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int, int, int, int) { atomicAdd(&hist[bin], 1u); });
+  }
+  __syncthreads();
+  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x)
+  {
+    base[k] = hist[k] ? b.offset[k] + atomicAdd(&b.cursor[k], hist[k]) : 0u;
+    hist[k] = 0u;
+  }
+  __syncthreads();
+  for(uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+  {
+    uint32_t z24;
+    int x0, x1, y0, y1;
+    if(splat_unpack(b.proj[i], z24, x0, x1, y0, y1))
+      splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int rx0, int rx1, int ry0, int ry1) {
+        const uint32_t rank = atomicAdd(&hist[bin], 1u);
+        b.records[base[bin] + rank] = make_uint4((uint32_t)i, z24, (uint32_t)rx0 | ((uint32_t)rx1 << 8) | ((uint32_t)ry0 << 16) | ((uint32_t)ry1 << 24), 0u);
+      });
+  }
+}
+
+constexpr int kSplatResolveThreads = 1024;   // 2 blocks of 64 KB LDS per CU: 32 waves, all the CU holds
+__global__ __launch_bounds__(kSplatResolveThreads) void splat_resolve_bins_kernel(const trt_point* __restrict__ pts, const SplatArgs a, const SplatBins b,
+                                                                                  float4 clear, float4* rgba)
+{
+  __shared__ unsigned long long keys[kBinW * kBinH];
+  for(uint32_t k = threadIdx.x; k < kBinW * kBinH; k += blockDim.x) keys[k] = kSplatClear;
+  __syncthreads();
+  const uint32_t bin = blockIdx.x, cnt = b.count[bin], off = b.offset[bin];
+  for(uint32_t r = threadIdx.x; r < cnt; r += blockDim.x)
+  {
+    const uint4 rec = b.records[off + r];
+    const unsigned long long key = ((unsigned long long)rec.y << 32) | (unsigned long long)rec.x;
+    const uint32_t x0 = rec.z & 255u, x1 = (rec.z >> 8) & 255u, y0 = (rec.z >> 16) & 255u, y1 = rec.z >> 24;
+    for(uint32_t y = y0; y < y1; ++y)
+      for(uint32_t x = x0; x < x1; ++x)
+        atomicMin(&keys[y * kBinW + x], key);
+  }
+  __syncthreads();
+  if(threadIdx.x == 0) b.count[bin] = 0u;   // the next call counts from zero
+  const uint32_t ox = (bin % b.bins_x) * kBinW, oy = (bin / b.bins_x) * kBinH;
+  // the colour gather is a dependent random 16-B read per covered pixel: four of them in flight per lane
+  constexpr uint32_t kU = 4;
+  for(uint32_t k0 = threadIdx.x; k0 < kBinW * kBinH; k0 += kU * blockDim.x)
+  {
+    unsigned long long key[kU];
+    float4 c[kU];
+#pragma unroll
+    for(uint32_t u = 0; u < kU; ++u)
+    {
+      const uint32_t k = k0 + u * blockDim.x;
+      key[u] = k < kBinW * kBinH ? keys[k] : kSplatClear;
+    }
+#pragma unroll
+    for(uint32_t u = 0; u < kU; ++u)
+    {
+      c[u] = clear;
+      if(key[u] != kSplatClear)
+      {
+        const float4 pc = reinterpret_cast<const float4*>(pts)[2 * (size_t)(uint32_t)key[u] + 1];
+        c[u] = make_float4(pc.x, pc.y, pc.z, 1.0f);   // o_color = vec4(current.color.xyz, 1.0)  (frag_shader.frag:44)
+      }
+    }
+#pragma unroll
+    for(uint32_t u = 0; u < kU; ++u)
+    {
+      const uint32_t k = k0 + u * blockDim.x;
+      const uint32_t x = ox + (k % kBinW), y = oy + (k / kBinW);
+      if(k < kBinW * kBinH && x < a.W && y < a.H)
+        rgba[(size_t)y * a.W + x] = c[u];
+    }
   }
 }
 
@@ -1296,22 +1493,48 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(const unsigned long 
   }
 }
 
+uint32_t splat_bins(uint32_t W, uint32_t H, float point_size, uint64_t n_points, const Tuning& tn)
+{
+  const uint64_t nb = (uint64_t)((W + kBinW - 1) / kBinW) * ((H + kBinH - 1) / kBinH);
+  if(tn.splat_variant == 0 || nb > kSplatMaxBins || W > kSplatMaxDim || H > kSplatMaxDim || !(point_size <= 32.0f) || 4 * n_points > 0xffffffffull)
+    return 0;   // the one-pass form
+  return (uint32_t)nb;
+}
+
 hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp, uint32_t W, uint32_t H,
-                        const float* clear, float point_size, unsigned long long* keys, float* rgba, int n_cus,
+                        const float* clear, float point_size, const SplatScratch& sc, float* rgba, int n_cus,
                         const Tuning& tn, hipStream_t stream)
 {
+  SplatArgs a;
+  for(int i = 0; i < 16; ++i) a.vp[i] = vp[i];
+  a.W = W; a.H = H; a.half = point_size * 0.5f;
+  if(sc.n_bins)
+  {
+    SplatBins b;
+    b.bins_x = (W + kBinW - 1) / kBinW; b.bins_y = (H + kBinH - 1) / kBinH; b.n_bins = sc.n_bins;
+    // fixed layout whatever n_bins is: the count words of one call never alias another call's offsets
+    b.count = sc.bin_words; b.offset = sc.bin_words + kSplatMaxBins; b.cursor = sc.bin_words + 2 * (size_t)kSplatMaxBins;
+    b.records = reinterpret_cast<uint4*>(sc.records);
+    b.proj    = reinterpret_cast<uint2*>(sc.proj);
+    if(n_points)
+    {
+      const uint32_t chunks = (uint32_t)((n_points + kSplatChunk - 1) / kSplatChunk);
+      hipLaunchKernelGGL(splat_count_kernel, dim3(chunks), dim3(256), sc.n_bins * sizeof(uint32_t), stream, pts, n_points, a, b);
+      hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, stream, b);
+      hipLaunchKernelGGL(splat_scatter_kernel, dim3(chunks), dim3(256), 2 * sc.n_bins * sizeof(uint32_t), stream, n_points, b);
+    }
+    hipLaunchKernelGGL(splat_resolve_bins_kernel, dim3(sc.n_bins), dim3(kSplatResolveThreads), 0, stream, pts, a, b,
+                       make_float4(clear[0], clear[1], clear[2], clear[3]), reinterpret_cast<float4*>(rgba));
+    return hipGetLastError();
+  }
+  unsigned long long* keys = sc.keys;
   uint64_t npx = (uint64_t)W * H, cap = (uint64_t)n_cus * 16;
   if(tn.splat_blocks_per_cu) cap = (uint64_t)n_cus * tn.splat_blocks_per_cu;
   if(cap == 0) cap = 1;
   auto grid = [&](uint64_t n) { const uint64_t w = (n + 255) / 256; return dim3((uint32_t)(w < cap ? (w ? w : 1) : cap)); };
   hipLaunchKernelGGL(splat_clear_kernel, grid(npx), dim3(256), 0, stream, keys, npx);
   if(n_points)
-  {
-    SplatArgs a;
-    for(int i = 0; i < 16; ++i) a.vp[i] = vp[i];
-    a.W = W; a.H = H; a.half = point_size * 0.5f;
     hipLaunchKernelGGL(splat_points_kernel, grid(n_points), dim3(256), 0, stream, pts, n_points, a, keys);
-  }
   hipLaunchKernelGGL(splat_resolve_kernel, grid(npx), dim3(256), 0, stream, keys, npx, pts,
                      make_float4(clear[0], clear[1], clear[2], clear[3]), reinterpret_cast<float4*>(rgba));
   return hipGetLastError();

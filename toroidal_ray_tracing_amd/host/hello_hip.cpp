@@ -204,7 +204,13 @@ void HelloHip::writeRenderedRays(const char* dir)
 
 void HelloHip::writeColorImage(const char* dir)
 {
-  std::ofstream outfile(std::string(dir) + "data/renderedColor" + std::to_string(m_pcRay.rho) + ".txt");
+  writeColorImageAs(std::string(dir) + "data/renderedColor" + std::to_string(m_pcRay.rho) + ".txt");
+}
+
+void HelloHip::writeColorImageAs(const std::string& path)
+{
+  std::ofstream outfile(path);
+  if(!outfile) throw std::runtime_error("cannot write " + path);
   for(uint32_t y = 0; y < m_size.height; ++y)
     for(uint32_t x = 0; x < m_size.width; ++x)
     {
@@ -221,6 +227,23 @@ void HelloHip::drawPost(void* stream)
   const size_t n = (size_t)m_size.width * m_size.height;
   if(!m_dPost) hipCheck(hipMalloc((void**)&m_dPost, n * 4), "hipMalloc(post)");
   check(trt_post_dev(m_ctx, m_dColor, n, nullptr, m_dPost, stream), "HelloHip::drawPost");
+}
+
+void HelloHip::writePostImagePPM(const std::string& path) const
+{
+  const size_t n = (size_t)m_size.width * m_size.height;
+  if(m_hostPost.size() != n * 4) throw std::runtime_error("writePostImagePPM: call drawPost() and copyPostImage() first");
+  std::ofstream out(path, std::ios::binary);
+  if(!out) throw std::runtime_error("cannot write " + path);
+  out << "P6\n" << m_size.width << " " << m_size.height << "\n255\n";
+  std::vector<uint8_t> rgb(n * 3);
+  for(size_t i = 0; i < n; ++i)
+  {
+    rgb[3 * i] = m_hostPost[4 * i];
+    rgb[3 * i + 1] = m_hostPost[4 * i + 1];
+    rgb[3 * i + 2] = m_hostPost[4 * i + 2];
+  }
+  out.write(reinterpret_cast<const char*>(rgb.data()), (std::streamsize)rgb.size());
 }
 
 void HelloHip::copyPostImage(void* stream)

@@ -56,11 +56,18 @@ public:
   void writeRenderedPosition(const char* dir);  // dir + "data/renderedPosition<rho>.txt": "x y z\n", index x*H+y
   void writeRenderedRays(const char* dir);      // dir + "data/origins.txt", "data/directions.txt"
   void writeColorImage(const char* dir);        // dir + "data/renderedColor<rho>.txt": row-major "r g b\n"
+  // the same dump under an explicit name — ray_tracing__before_second/hello_vulkan.cpp:781-825 writes the
+  // re-projected image to dir + "data/<scene>ptCloudImage_10.txt", ray_tracing_reflections/…:1065-1110 the
+  // ground truth to dir + "data/<scene>gTruth.txt": one "r g b\n" line per pixel, row-major
+  void writeColorImageAs(const std::string& path);
 
   // --- post pass (drawPost, ray_tracing_reflections/hello_vulkan.cpp:560-579 + post.frag) ------
   void drawPost(void* stream);              // tonemap m_dColor -> 8-bit image (pow(c, 1/2.2))
   void copyPostImage(void* stream);         // device -> host
   const std::vector<uint8_t>& postImage() const { return m_hostPost; }
+  // The presented image as a file: binary PPM (P6, 8-bit RGB) of the tonemapped frame — what the swapchain
+  // shows after post.frag (REFL/shaders/post.frag:33-37); call drawPost() + copyPostImage() first.
+  void writePostImagePPM(const std::string& path) const;
 
   // --- point-cloud re-projection (ray_tracing__before_second) -------------------------------
   // loadPoints (SEC/hello_vulkan.cpp:496-628): "x y z" per line, "-nan" -> numeric_limits<float>::lowest()
