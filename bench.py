@@ -134,7 +134,9 @@ def cpu_baseline(sc, g, pc, W, H):
     from oracle import oracle
     from toroidal_ray_tracing_amd import abi, camera
     L = oracle.lib()
-    cores = oracle.max_threads()
+    # every core this process may run on (torch.distributed.run exports OMP_NUM_THREADS=1 for its ranks: the
+    # explicit num_threads clause of the oracle overrides it)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else oracle.max_threads()
     rgba = np.zeros((H, W, 4), np.float32)
     hits = abi.alloc_hits(W * H)
     for v in hits.values():
@@ -425,7 +427,8 @@ def worker(a, world, rank, local):
     if world > 1:
         dist.all_reduce(tests)
     cnt = dict(zip(keys, (int(v) for v in tests.tolist())))
-    assert cnt["pixels"] == W * H and cnt["primary_tests"] == W * H * sc.n_tori
+    if not os.environ.get("TRT_DEBUG_SKIP"):   # a timing ablation of the tuning build renders part of the frame only
+        assert cnt["pixels"] == W * H and cnt["primary_tests"] == W * H * sc.n_tori
 
     for _ in range(a.warmup):
         for _ in range(F):

@@ -17,7 +17,10 @@ def one(pattern):
 
 stats = one("trace/*/*kernel_stats.csv")
 if stats:
-    shutil.copy(stats, os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+    # this library's kernels only (bench.py's secondary configurations build their inputs with torch kernels)
+    lines = open(stats).read().splitlines()
+    keep = [lines[0]] + [ln for ln in lines[1:] if "trt::" in ln.split(",")[0]]
+    open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w").write("\n".join(keep) + "\n")
 for name in ("bench.json", "bench_under_rocprof.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
@@ -49,5 +52,5 @@ traffic["size"], traffic["depth"] = 4096, 5   # the workload of the passes (benc
 traffic[variant] = {"hbm_bytes_per_launch": fetch + write, "write_bytes": write, "fetch_bytes_corrected": fetch,
                     "note": "classify + render kernels of one frame; FETCH_SIZE doubled per the gfx950 correction"}
 json.dump(traffic, open(os.path.join(dst, f"traffic_{rnd}.json"), "w"), indent=1)
-print(open(os.path.join(dst, f"{rnd}_kernel_stats.csv")).read() if stats else "no kernel stats")
+print("\n".join(ln[:160] for ln in open(os.path.join(dst, f"{rnd}_kernel_stats.csv")).read().splitlines()) if stats else "no kernel stats")
 print(json.dumps(traffic, indent=1))

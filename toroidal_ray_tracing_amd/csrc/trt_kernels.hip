@@ -547,12 +547,30 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
 // accumulators zero for the next frame.  A frame therefore depends on no other frame: no memset, no
 // double buffering, nothing that distinguishes eager launches from hipGraph replays.  One returning
 // atomic per block (256 blocks at 4096²).
-__device__ __forceinline__ void classify_publish(const RenderArgs& a)
+// The ticket is drawn right after the barrier that follows the reservations and BEFORE the block's list
+// writes (classify_ticket), so that the latency of the returning atomic hides behind those stores; the
+// publication itself (classify_publish) comes last.  (The list entries are read by the NEXT kernel: the
+// kernel boundary orders them, not the ticket.)
+// The tickets are sharded over eight words (a.counters[8 + blockIdx % 8]): 256 returning atomics on ONE word
+// take ≈3 µs (≈12 ns each, MI355X_MICROARCH.md "fanin") at the tail of a 9-µs kernel; the last block of a shard
+// draws a second-level ticket on a.counters[2], and the last of those publishes.
+__device__ __forceinline__ unsigned int classify_ticket(const RenderArgs& a)
 {
-  if(threadIdx.x == 0)   // the reservations of threads 0 and 1 returned before the barrier above
+  return threadIdx.x == 0 ? atomicAdd(&a.counters[8u + (blockIdx.x & 7u)], 1u) : 0u;   // the reservations of threads 0 and 1 have returned
+}
+
+__device__ __forceinline__ void classify_publish(const RenderArgs& a, unsigned int ticket)
+{
+  if(threadIdx.x == 0)
   {
-    const unsigned int ticket = atomicAdd(&a.counters[2], 1u);
-    if(ticket == gridDim.x - 1)
+    const unsigned int shard = blockIdx.x & 7u, in_shard = (gridDim.x - shard + 7u) >> 3, n_shards = gridDim.x < 8u ? gridDim.x : 8u;
+    bool last = false;
+    if(ticket == in_shard - 1)
+    {
+      atomicExch(&a.counters[8u + shard], 0u);
+      last = atomicAdd(&a.counters[2], 1u) == n_shards - 1;
+    }
+    if(last)
     {
       const unsigned int n_live = atomicExch(&a.counters[0], 0u), n_clear = atomicExch(&a.counters[1], 0u);
       a.counts[0] = n_live < a.cap_live ? n_live : a.cap_live;
@@ -613,6 +631,7 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
     block_base[threadIdx.x] = sum ? atomicAdd(&a.counters[threadIdx.x], sum) : 0u;
   }
   __syncthreads();
+  const unsigned int ticket = classify_ticket(a);
   const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1];
   if(clear && ic < a.cap_clear)
     a.tiles_clear[ic] = tx0 | (ty << 16);
@@ -620,7 +639,7 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   for(uint32_t j = 0; j < nlive; ++j)
     if(il + j < a.cap_live)
       a.tiles_live[il + j] = (tx0 + j) | (ty << 16);
-  classify_publish(a);
+  classify_publish(a, ticket);
 }
 
 // Second, finer classification (RenderArgs::fine): one lane per 8×8 tile; four consecutive lanes are one MACRO tile (32×8 pixels: one 128-B line
@@ -683,12 +702,13 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(co
     block_base[threadIdx.x] = sum ? atomicAdd(&a.counters[threadIdx.x], sum) : 0u;
   }
   __syncthreads();
+  const unsigned int ticket = classify_ticket(a);
   const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1], il = block_base[0] + wave_cnt[0][wave] + pre[0];
   if(nclear && ic < a.cap_clear)
     a.tiles_clear[ic] = tx | (ty << 16);
   if(nlive && il < a.cap_live)
     a.tiles_live[il] = tx | (ty << 16) | (clear ? kTileMissFlag : 0u);
-  classify_publish(a);
+  classify_publish(a, ticket);
 }
 
 // ------------------------------------------------------------------------------------------
