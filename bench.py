@@ -134,9 +134,15 @@ def cpu_baseline(sc, g, pc, W, H):
     from oracle import oracle
     from toroidal_ray_tracing_amd import abi, camera
     L = oracle.lib()
-    # every core this process may run on (torch.distributed.run exports OMP_NUM_THREADS=1 for its ranks: the
-    # explicit num_threads clause of the oracle overrides it)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else oracle.max_threads()
+    # threads = OpenMP's default team (every hardware thread it sees), capped by the cgroup's CPU quota when the
+    # box has one: oversubscribing a 16-CPU share with 256 threads only measures the scheduler
+    cores = oracle.max_threads()
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     rgba = np.zeros((H, W, 4), np.float32)
     hits = abi.alloc_hits(W * H)
     for v in hits.values():

@@ -45,6 +45,14 @@ if "parts" in cases:
         os.environ["TRT_DEBUG_SKIP"] = str(skip); _tuning.reload(tr)
         show(nm, timeit(lambda: tr.render_dev(sc1, g, pc, W, W, rgba.data_ptr(), hit_ptrs=hp, stream=s.cuda_stream)), 44 * W * W)
     os.environ.pop("TRT_DEBUG_SKIP"); _tuning.reload(tr)
+if "c5" in cases:
+    W5 = 8192
+    rgba5 = torch.empty(W5, W5, 4, device=dev)
+    hits5 = {k: torch.empty(W5 * W5, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
+    hp5 = {k: v.data_ptr() for k, v in hits5.items()}
+    g5 = camera.baseline_camera(W5, W5)
+    show("C5 shape 8192^2 on one GPU", timeit(lambda: tr.render_dev(sc1, g5, pc, W5, W5, rgba5.data_ptr(), hit_ptrs=hp5, stream=s.cuda_stream), reps=10), 44 * W5 * W5)
+    del rgba5, hits5
 if "persist" in cases:
     tr.set_render_variant("persistent")
     show("C3 persistent variant", timeit(lambda: tr.render_dev(sc1, g, pc, W, W, rgba.data_ptr(), hit_ptrs=hp, stream=s.cuda_stream)), 44 * W * W)

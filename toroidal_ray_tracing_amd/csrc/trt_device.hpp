@@ -578,7 +578,20 @@ struct WorkCount {
   uint32_t evals  = 0;  // evaluations of (f, f') by the default solver's walk
 };
 
-template <class Real, bool DK = false>
+// Which form of the walk a kernel runs (both visit the same points and take the same decisions):
+//   kWalkNested  TorusTest::walk(): cheapest per trip, but forward runs, backward runs and the pieces of
+//                different lanes execute one after the other — the choice for COHERENT rays (render kernels:
+//                config 4 −5 %, against the table);
+//   kWalkTable   TorusTest::step(), first trip peeled: every lane advances on every trip whatever its piece and
+//                mode — the choice for INCOHERENT rays (trt_trace on random aimed rays: 0.087 against 0.113 ms).
+enum : int { kWalkNested = 0, kWalkTable = 1 };
+#ifdef TRT_RENDER_WALK_TABLE   // timing builds: the table in the render kernels too
+constexpr int kRenderWalk = kWalkTable;
+#else
+constexpr int kRenderWalk = kWalkNested;
+#endif
+
+template <class Real, bool DK = false, int WALK = kRenderWalk>
 __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
                                                 Real dz_, Real dd, Real inv_dd, Real tmin, Real tmax,
                                                 const TorusK<Real>& T, Real& t_out, WorkCount& wc, int alt = 1)
@@ -602,22 +615,23 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
   }
   else
   {
-#ifdef TRT_WALK_TABLE
-    // the resumable state machine of the persistent kernel, first trip peeled (right after setup()
-    // every field the transitions read is a known constant, so the compiler folds step())
-    ++wc.evals;
-    bool run = q.step();
-    while(run)
+    if(WALK == kWalkTable)
     {
+      // the resumable state machine of the persistent kernel, first trip peeled (right after setup()
+      // every field the transitions read is a known constant, so the compiler folds step())
       ++wc.evals;
-      if(__any(!q.iterating()))
-        run = q.step();
-      else
-        run = q.step_iter();
+      bool run = q.step();
+      while(run)
+      {
+        ++wc.evals;
+        if(__any(!q.iterating()))
+          run = q.step();
+        else
+          run = q.step_iter();
+      }
     }
-#else
-    q.walk(wc.evals);
-#endif
+    else
+      q.walk(wc.evals);
   }
   return q.finish(dx_, dy_, dz_, tmin, tmax, T, t_out);
 }
@@ -657,11 +671,11 @@ __device__ __forceinline__ bool round_t(double t, float tmin, float tmax, float&
 }
 
 // One ray against torus i over the open interval (tmin, tmax); t rounded to FP32.
-template <class Real, bool DK = false>
+template <class Real, bool DK = false, int WALK = kRenderWalk>
 __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t, WorkCount& wc)
 {
   Real tt;
-  if(!torus_first_hit<Real, DK>((Real)r.ox, (Real)r.oy, (Real)r.oz, (Real)r.dx, (Real)r.dy, (Real)r.dz, r.dd, r.inv_dd, (Real)r.tmin, (Real)tmax,
+  if(!torus_first_hit<Real, DK, WALK>((Real)r.ox, (Real)r.oy, (Real)r.oz, (Real)r.dx, (Real)r.dy, (Real)r.dz, r.dd, r.inv_dd, (Real)r.tmin, (Real)tmax,
                                 torus_k<Real>(S, i), tt, wc, S.dk))
     return false;
   return round_t(tt, tmin, tmax, t);
@@ -672,7 +686,7 @@ __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Rea
 // test ends at the closest hit so far: behind an enclosing shell the remaining tests end in
 // their window clip without a Newton step.  Equal t keeps the torus tested first.
 // Returns the torus index or -1; `tests` counts ray–torus tests.
-template <class Real, bool DK = false>
+template <class Real, bool DK = false, int WALK = kRenderWalk>
 __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
                                            float& t_out, uint32_t& tests, WorkCount& wc)
 {
@@ -685,7 +699,7 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
     const int i = S.order[k];
     float t;
     ++tests;
-    if(torus_hit<Real, DK>(S, i, r, tmin, min_(tmax, best), t, wc))
+    if(torus_hit<Real, DK, WALK>(S, i, r, tmin, min_(tmax, best), t, wc))
     {
       best = t;
       id   = i;
