@@ -127,7 +127,7 @@ def launch(a):
 def cpu_baseline(sc, g, pc, W, H):
     """The oracle (a scalar C port — the reference has NO CPU path) timed on this host's cores:
     whole frames of the same workload, OpenMP over 64-pixel blocks, until ~15 s of aggregate CPU time
-    have been spent (wall x threads), at most 8 frames; then a bounded 1-thread sample (rows of the
+    have been spent (wall x threads), at most 64 frames; then a bounded 1-thread sample (rows of the
     same frame through the image centre, ~5-10 s), and BASELINE.md's configs 1 and 2 (256² and
     2048², maxDepth 1) on one thread and on all cores."""
     import numpy as np
@@ -159,7 +159,7 @@ def cpu_baseline(sc, g, pc, W, H):
 
     run(g, pc, W, H, 0, min(H, 64), cores)  # warm up the thread pool and the page tables
     t, frames = 0.0, 0
-    while frames < 8 and (frames < 2 or t * cores < 15.0):
+    while frames < 64 and (frames < 2 or t * cores < 15.0):
         dt, st = run(g, pc, W, H, 0, H, cores)
         t += dt
         frames += 1

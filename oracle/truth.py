@@ -96,3 +96,101 @@ def normal(P, C, R):
     q = np.stack([p[:, 0] * R / rho, np.zeros_like(rho), p[:, 2] * R / rho], 1)
     v = p - q
     return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# Closed-form families: rays whose intersection with the torus reduces to circles
+# ---------------------------------------------------------------------------------------------
+# Three families of rays meet a torus (centre C, axis +y, radii R, r) in sections that are circles, so the hit
+# parameter is a square root away — no quartic, no iteration, nothing shared with any solver in this repository:
+#   "equatorial"  origin and direction in the plane y = Cy: the section is the annulus between the circles of radius
+#                 R - r and R + r around C — every crossing of either circle is a surface crossing;
+#   "meridional"  origin and direction in the plane z = Cz (a plane through the axis): the section is the two
+#                 tube circles of radius r around (Cx ± R, Cy);
+#   "axial"       direction ±y: the ray stays at distance rho from the axis and meets the tube circle
+#                 (rho - R)² + y² = r².
+# closed_form_family() draws rays of a family and returns, per ray, the smallest crossing parameter beyond tmin
+# (inf = miss), the outward normal there, and a margin flag: False where a discriminant is so close to zero (or a
+# crossing so close to tmin) that FP32 arithmetic may legitimately classify the ray the other way.
+def _circle_roots(ox, oy, dx, dy, cx, cy, rad):
+    """parameters t of (o + t d) on the circle |p - c| = rad in a plane; d need not be unit; nan where none"""
+    ex, ey = ox - cx, oy - cy
+    a = dx * dx + dy * dy
+    b = ex * dx + ey * dy
+    c = ex * ex + ey * ey - rad * rad
+    disc = b * b - a * c
+    with np.errstate(invalid="ignore"):
+        sq = np.sqrt(disc)
+    return np.stack([(-b - sq) / a, (-b + sq) / a], -1), disc / (a * rad * rad)   # disc relative to (a rad²)
+
+
+def closed_form_family(family, n, seed, C=(0.0, 0.0, 0.0), R=1.0, r=0.25, tmin=0.001, box=3.0):
+    rng = np.random.default_rng(seed)
+    C = np.asarray(C, np.float64)
+    o = np.tile(C, (n, 1))
+    d = np.zeros((n, 3))
+    # the rays are drawn, rounded to FP32 (what every FP32 consumer sees) and the closed form is evaluated on the
+    # ROUNDED rays: zero components stay exactly zero, so a ray stays exactly in its plane / parallel to the axis
+    # (C must be exactly representable in FP32)
+    def f32(a):
+        return a.astype(np.float32).astype(np.float64)
+    if family == "equatorial":
+        o[:, [0, 2]] += rng.uniform(-box, box, (n, 2)) * (R + r)
+        ang = rng.uniform(0, 2 * np.pi, n)
+        d[:, 0], d[:, 2] = np.cos(ang), np.sin(ang)
+        o, d = f32(o), f32(d)
+        roots, margins = [], []
+        for rad in (R + r, R - r):
+            t, m = _circle_roots(o[:, 0], o[:, 2], d[:, 0], d[:, 2], C[0], C[2], rad)
+            roots.append(t)
+            margins.append(m)
+    elif family == "meridional":
+        o[:, [0, 1]] += rng.uniform(-box, box, (n, 2)) * (R + r)
+        ang = rng.uniform(0, 2 * np.pi, n)
+        d[:, 0], d[:, 1] = np.cos(ang), np.sin(ang)
+        # 70 % of the rays are aimed at a point within 1.5 r of one of the two tube circles (thin tubes are small targets)
+        aim = rng.uniform(size=n) < 0.7
+        tgt = np.stack([C[0] + np.where(rng.uniform(size=n) < 0.5, R, -R), np.full(n, C[1])], 1) + rng.uniform(-1.5 * r, 1.5 * r, (n, 2))
+        v = tgt - o[:, :2]
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        d[aim, 0], d[aim, 1] = v[aim, 0], v[aim, 1]
+        o, d = f32(o), f32(d)
+        roots, margins = [], []
+        for sx in (+1.0, -1.0):
+            t, m = _circle_roots(o[:, 0], o[:, 1], d[:, 0], d[:, 1], C[0] + sx * R, C[1], r)
+            roots.append(t)
+            margins.append(m)
+    elif family == "axial":
+        o[:, [0, 2]] += rng.uniform(-(R + 2 * r), R + 2 * r, (n, 2))
+        o[:, 1] += rng.uniform(-box, box, n)
+        d[:, 1] = np.where(rng.uniform(size=n) < 0.5, 1.0, -1.0)
+        o, d = f32(o), f32(d)
+        rho = np.hypot(o[:, 0] - C[0], o[:, 2] - C[2])
+        disc = r * r - (rho - R) ** 2
+        with np.errstate(invalid="ignore"):
+            h = np.sqrt(disc)
+        ys = np.stack([C[1] - h, C[1] + h], -1)
+        roots = [(ys - o[:, 1:2]) / d[:, 1:2]]
+        margins = [disc / (r * r)]
+    else:
+        raise ValueError(family)
+    t_all = np.concatenate(roots, 1)
+    with np.errstate(invalid="ignore"):
+        t_all = np.where(t_all > tmin, t_all, np.inf)
+    t_all = np.where(np.isnan(t_all), np.inf, t_all)
+    t = t_all.min(1)
+    # margin: every discriminant away from 0 (tangency), every crossing away from tmin, o not on the surface
+    ok = np.ones(n, bool)
+    for m in margins:
+        ok &= np.abs(m) > 1e-3
+    every = np.concatenate(roots, 1)
+    with np.errstate(invalid="ignore"):
+        ok &= ~np.any(np.abs(every - tmin) < 1e-3, axis=1)
+    # outward normal N = (P - q)/r, q the nearest point of the centre circle (SURVEY.md §8a T4)
+    P = o + np.where(np.isfinite(t), t, 0.0)[:, None] * d
+    pl = P - C
+    rho = np.hypot(pl[:, 0], pl[:, 2])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = np.stack([pl[:, 0] * R / rho, np.zeros(n), pl[:, 2] * R / rho], 1)
+    N = (pl - q) / r
+    return o.astype(np.float32), d.astype(np.float32), t, N, ok

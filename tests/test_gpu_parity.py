@@ -82,6 +82,32 @@ def test_trace_vs_golden_fp64_truth(tr, name):
     assert (np.abs(got["t"][both] - z["t"][both]) / np.maximum(1, z["t"][both])).max() < 1e-5
 
 
+@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("family", ["equatorial", "meridional", "axial"])
+def test_trace_vs_closed_form_families(tr, family, precision):
+    """The HIP path against closed-form truth that involves no quartic solver at all (oracle/truth.py::
+    closed_form_family: rays that meet the torus in circles): classification equal on every non-tangent ray,
+    t within 1e-5 relative (2e-6 with the FP64 solve), normals within 2e-5·R/r — the north_star tolerance,
+    checked against arithmetic that shares nothing with the kernels or the C oracle."""
+    from oracle import truth
+    for C, R, r in (((0.0, 0.0, 0.0), 1.0, 0.25), ((0.5, -0.25, 1.0), 2.0, 0.125)):
+        o, d, t, N, ok = truth.closed_form_family(family, 100_000, 78, C=C, R=R, r=r)
+        sc = camera.single_torus_scene(center=C, R=R, r=r)
+        tr.set_solver(precision)
+        try:
+            got = tr.trace(sc, o, d)
+        finally:
+            tr.set_solver(abi.TRT_SOLVE_F32)
+        hit_t, hit_g = np.isfinite(t), np.isfinite(got["t"])
+        assert not np.any((hit_t != hit_g) & ok)
+        both = hit_t & hit_g & ok
+        assert both.sum() > 5000
+        rel = np.abs(got["t"][both] - t[both]) / np.maximum(1.0, t[both])
+        assert rel.max() < (2e-6 if precision == abi.TRT_SOLVE_F64 else 1e-5), rel.max()
+        Ng = np.stack([got["nx"], got["ny"], got["nz"]], 1)[both]
+        assert np.abs(Ng - N[both]).max() < 2e-5 * max(1.0, R / r)
+
+
 def test_trace_edge_cases(tr, oracle):
     sc = camera.single_torus_scene()
     # empty input

@@ -108,6 +108,30 @@ def test_oracle_vs_fp64_truth(oracle, name, precision):
             assert np.abs(N[m] - Nt).max() < 2e-5 * R / r
 
 
+@pytest.mark.parametrize("precision", [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("torus", [((0.0, 0.0, 0.0), 1.0, 0.25), ((0.5, -0.25, 1.0), 2.0, 0.125), ((0.0, 0.0, 0.0), 1.0, 0.875)],
+                         ids=["baseline", "thin_offset", "fat"])
+@pytest.mark.parametrize("family", ["equatorial", "meridional", "axial"])
+def test_closed_form_families(oracle, family, torus, precision):
+    """A pin of the torus arithmetic that shares nothing with any solver here: rays in the equatorial plane, in a
+    plane through the axis, and parallel to the axis meet the torus in CIRCLES, so the first crossing is a square root
+    away (oracle/truth.py::closed_form_family).  20,000 rays per family and torus: hit/miss equal on every ray that
+    is not within 1e-3 of a tangency, t within 1e-5 relative (2e-6 with the FP64 solve), normals within 2e-5 /(r/R)."""
+    C, R, r = torus
+    # centres with exactly representable coordinates keep the rays exactly in their planes after rounding to FP32
+    o, d, t, N, ok = truth.closed_form_family(family, 20_000, 77, C=C, R=R, r=r)
+    sc = camera.single_torus_scene(center=C, R=R, r=r)
+    got, _ = oracle.trace(sc, o, d, precision=precision, nthreads=8)
+    hit_t, hit_g = np.isfinite(t), np.isfinite(got["t"])
+    assert 0.05 < hit_t.mean() < 0.98
+    assert not np.any((hit_t != hit_g) & ok), int(((hit_t != hit_g) & ok).sum())
+    both = hit_t & hit_g & ok
+    rel = np.abs(got["t"][both] - t[both]) / np.maximum(1.0, t[both])
+    assert rel.max() < (2e-6 if precision == abi.TRT_SOLVE_F64 else 1e-5), rel.max()
+    Ng = np.stack([got["nx"], got["ny"], got["nz"]], 1)[both]
+    assert np.abs(Ng - N[both]).max() < 2e-5 * max(1.0, R / r)
+
+
 def test_oracle_fresh_random_rays_vs_truth(oracle):
     """A seed that is not in the fixtures, several shapes."""
     for k, (c, R, r) in enumerate([((0, 0, 0), 1.0, 0.4), ((1, 2, -1), 3.0, 1.0), ((0, 0, 0), 1.0, 0.9)]):
