@@ -184,7 +184,12 @@ int trt_trace_dev(trt_ctx* ctx, const trt_rays* in_dev, const trt_scene* scene,
 int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
                uint32_t W, uint32_t H, int camera, float* rgba_out, trt_hits* first_hit_out);
 /* The *_dev entry points allocate nothing and synchronise nothing once the ctx's scratch has been
- * sized by a first call, so a frame loop on them can be captured into a hipGraph and replayed.
+ * sized by a first call with the same sizes, and they put only kernel nodes on the stream: a frame loop
+ * on them can be captured into a hipGraph, replayed, and mixed with eager frames in any order (every
+ * frame leaves the ctx's tile-list counters as it found them).  A call that would have to grow the
+ * scratch, or to upload the tables of a new toroidal-camera frame, while `stream` is being captured
+ * returns TRT_E_INVALID instead of allocating inside the capture; growing the scratch later frees the
+ * old block, which invalidates graphs captured before.
  *
  * Rows [row_begin,row_end) only; outputs are indexed relative to the FULL image, so a
  * rank that owns a row band passes pointers to the full-frame buffers (or to buffers

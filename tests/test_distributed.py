@@ -140,17 +140,18 @@ def _bench(args, env=None):
 
 
 @pytest.mark.timeout(300)
-def test_bench_launcher_starts_the_ranks_itself():
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_launcher_starts_the_ranks_itself(n):
     """`python bench.py --gpus 2` (no torchrun around it): the parent spawns 2 ranks, relays rank 0's line, and
     that line says n_gpus 2.  --backend gloo --dry-run is the CPU rehearsal: rank-coded rows instead of rendered
     ones, the REAL TiledFrame gathers, every rank checks the assembled frame."""
     import json
-    p = _bench(["--gpus", "2", "--backend", "gloo", "--dry-run", "--size", "64"])
+    p = _bench(["--gpus", str(n), "--backend", "gloo", "--dry-run", "--size", "64"])
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["gathered_frame_ok"] is True and out["value"] is None
+    assert out["n_gpus"] == n and out["dry_run"] is True and out["gathered_frame_ok"] is True and out["value"] is None
 
 
 def test_bench_never_reports_the_wrong_job_size():

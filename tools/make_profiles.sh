@@ -12,10 +12,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --variant $V --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || tail -5 $OUT/trace.err
 # 2. HBM traffic, separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py --variant $V --steps 3 --warmup 1 --frames-per-step 4 --no-secondary --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err || tail -3 $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py --variant $V --steps 3 --warmup 1 --frames-per-step 4 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err || tail -3 $OUT/pmc_$C.err
 done
 # 3. issue / occupancy counters of the dominant kernel
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py --variant $V --steps 3 --warmup 1 --frames-per-step 4 --no-secondary --no-cpu-baseline > /dev/null 2> $OUT/pmc_SQ.err || tail -3 $OUT/pmc_SQ.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py --variant $V --steps 3 --warmup 1 --frames-per-step 4 --no-cpu-baseline > /dev/null 2> $OUT/pmc_SQ.err || tail -3 $OUT/pmc_SQ.err
 # 4. the un-profiled bench line, for comparison (never compare a profiled arm with an un-profiled one)
 python3 $R/bench.py --variant $V --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
 ls $OUT
