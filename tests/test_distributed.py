@@ -164,6 +164,7 @@ def test_bench_never_reports_the_wrong_job_size():
 
 
 def test_default_group_rows():
+    assert trtd.default_group_rows(4096, 8, 1) == 512 and trtd.default_group_rows(4096, 2, 1) == 2048
     assert trtd.default_group_rows(4096, 8) == 64 and trtd.default_group_rows(4096, 2) == 256
     assert trtd.default_group_rows(8192, 8) == 128 and trtd.default_group_rows(4096, 1) == 4096
     assert trtd.default_group_rows(64, 2) == 8 and trtd.default_group_rows(48, 3) == 8

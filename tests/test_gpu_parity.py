@@ -439,7 +439,7 @@ def test_config5_shape_tiled_on_one_gpu(tr):
         tr.render_dev(sc, g, pc, W, H, full.data_ptr(), hit_ptrs={"t": t_full.data_ptr(), "id": id_full.data_ptr()}, stream=s)
         torch.cuda.synchronize()
         st_full = tr.stats()
-        for group in (8, trtd.default_group_rows(H, parts)):
+        for group in (8, trtd.default_group_rows(H, parts), trtd.default_group_rows(H, parts, 1)):
             assert H % (group * parts) == 0
             asm = torch.zeros(H, W, 4, device=dev)          # the frame as the in-place gathers assemble it
             t_asm = torch.zeros(H, W, device=dev)

@@ -12,17 +12,19 @@ of the tiling is N consecutive groups = G·N consecutive image rows, group p of 
 rank p — so the all-gather of the ranks' c-th groups, ``all_gather_into_tensor(frame[c·G·N :
 (c+1)·G·N], local[c·G : (c+1)·G])``, lands every row AT ITS PLACE in the row-major frame: the
 gathered frame needs no de-interleaving copy (round 1 paid 2 × 268 MB of HBM traffic per frame
-for one).  G is chosen so that a frame has a handful of cycles (default 8): few, large
-collectives (xGMI is point-to-point, 7 links per GPU; RCCL spreads a large collective over all
-of them) and still an interleaving fine enough to balance the load (the torus sits in the
-middle rows).
+for one).  How many cycles: when the frame is gathered the step is bound by the collective, not by
+the render, so ONE cycle — plain row bands, one large collective per frame, no launch
+overhead of eight small ones (xGMI is point-to-point, 7 links per GPU; RCCL spreads a large
+collective over all of them); without a gather (`gather="none"`) eight cycles, an interleaving
+fine enough to balance the load (the torus sits in the middle rows).
 """
 import torch
 import torch.distributed as dist
 
 from . import abi
 
-DEFAULT_CYCLES = 8   # collectives per frame (when H allows it)
+DEFAULT_CYCLES = 8          # groups per rank without a gather (load balance)
+DEFAULT_CYCLES_GATHER = 1   # … and with one: a single collective per frame
 
 
 def default_group_rows(H, world, cycles=DEFAULT_CYCLES):
@@ -75,7 +77,7 @@ class TiledFrame:
             raise ValueError(f"gather={gather!r}")
         self.mode = mode if (world > 1 or force_collective) else "none"
         self.gather = self.mode != "none"
-        self.group_rows = group_rows or default_group_rows(H, world)
+        self.group_rows = group_rows or default_group_rows(H, world, DEFAULT_CYCLES_GATHER if self.gather else DEFAULT_CYCLES)
         if world > 1 and H % (self.group_rows * world) != 0:
             raise ValueError(f"H={H} must be a multiple of group_rows*world={self.group_rows * world}")
         self.cycles = H // (self.group_rows * world) if world > 1 else 1
