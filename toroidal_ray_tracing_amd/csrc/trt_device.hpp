@@ -598,16 +598,9 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
 {
   TorusTest<Real> q;
   ++wc.traced;
-#if defined(TRT_ABLATE) && TRT_ABLATE == 2   // timing ablation builds only (never shipped): no test at all
-  return false;
-#endif
   if(!q.setup(ox, oy, oz, dx_, dy_, dz_, dd, inv_dd, tmin, tmax, T))
     return false;
   ++wc.solved;
-#if defined(TRT_ABLATE) && TRT_ABLATE == 1   // … setup only, no walk
-  t_out = q.hi;
-  return q.hi > Real(1e30);
-#endif
   if(DK)
   {
     if(alt == 2) q.solve_ferrari(inv_dd, T.Rb2);   // wave-uniform: the scene's solver
