@@ -66,7 +66,7 @@ struct TorusK {   // per-torus constants of the solver
   Real r2;      // r²
   Real rpol;    // r/32: largest step the geometric polish may take
   Real k0;      // R² - r²
-  Real Rb2;     // (R+r)²·(1+2⁻⁹): squared radius of the slightly inflated bounding sphere / cylinder
+  Real Rb2;     // (R+r)²·(1+2⁻⁹): squared radius of the slightly inflated bounding sphere
   Real rs;      // r·(1+2⁻⁸): half height of the slightly inflated bounding slab |y| <= rs
   Real fourR2;  // 4R²
 };
@@ -172,21 +172,12 @@ struct TorusTest {
     const Real a     = fma_(dz_, dz_, dx_ * dx_);
     const Real b     = fma_(qz, dz_, qx * dx_);
     const Real c     = fma_(qz, qz, qx * qx);
-    // T1b: clip the window to the bounding cylinder ρ² <= Rb² and slab |y| <= rs (both slightly
-    // inflated, so the walk still starts strictly outside the torus).  The box holds only
-    // 1.5·r/(R+r) of the sphere's volume: most rays that pass the sphere but miss the torus end
-    // here without a single Newton step, and the others start next to the surface.
-    if(a > Real(0))
-    {
-      const Real disc = fma_(b, b, -(a * (c - T.Rb2)));
-      if(!(disc >= Real(0)))
-        return false;
-      const Real sq = sqrt_(disc), inv_a = Real(1) / a;
-      lo = max_(lo, (-b - sq) * inv_a);
-      hi = min_(hi, (sq - b) * inv_a);
-    }
-    else if(!(c <= T.Rb2))
-      return false;
+    // T1b: clip the window to the bounding slab |y| <= rs (slightly inflated, like the sphere, so that the walk still
+    // starts strictly outside the torus).  Sphere ∩ slab holds only ≈1.5·r/(R+r) of the sphere's volume: most rays that
+    // pass the sphere but miss the torus end here without a single Newton step, and the others start next to the surface.
+    // (Round 1 also clipped to the bounding CYLINDER of the same radius — a square root and a division per test for
+    // nothing: with q ⟂ d, sphere(u) − cylinder(u) = (dy·u + qy)² >= 0, so the sphere's interval always lies inside the
+    // cylinder's.)
     if(dy_ != Real(0))
     {
       const Real inv_dy = Real(1) / dy_;

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void render_static_kernel(const SceneK scene, 
 //     dist >= dl - Δo - (L + Δo)·θ,   dl = dist(C, centre line), L = |C - oc|,
 // and the tile is clear when that exceeds the sphere radius by 1.6 % + 1e-5·(L+1) — three
 // orders of magnitude above the FP32 rounding of the per-pixel test.  A second test does the
-// same for the bounding box (cylinder ∩ slab) TorusTest::setup() clips to, which removes the
+// same for the bounding box (cylinder ∩ slab — it contains the sphere ∩ slab that TorusTest::setup() clips to), which removes the
 // caps of the sphere's silhouette and everything behind the camera.  Anything doubtful
 // (NaN, wide tiles, origin near the sphere) is LIVE.  Tiles are appended to two compact lists
 // (one wave-aggregated atomic per list per wave); order within the lists is irrelevant.
@@ -482,7 +482,7 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
     // (1) every line of the bundle misses the bounding sphere
     if(dl - dO - (L + dO) * theta > rb * 1.015625f + 1e-5f * (L + 1.0f))
       continue;
-    // (2) the centre ray misses the bounding box (cylinder ∩ slab, the solid TorusTest::setup
+    // (2) the centre ray misses the bounding box (cylinder ∩ slab ⊇ sphere ∩ slab, the solid TorusTest::setup
     //     clips to) inflated by delta, the largest distance between a point of any ray of the
     //     bundle and the centre ray's point at the same parameter, over the parameters at which
     //     the sphere can be met (t <= L + rb): delta = Δo + (L + rb)·θ
