@@ -11,8 +11,9 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    files = glob.glob(os.path.join(src, pattern))
-    return files[0] if files else None
+    """newest match (gpurun_out/ accumulates the outputs of every run of make_profiles.sh)"""
+    files = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    return files[-1] if files else None
 
 
 stats = one("trace/*/*kernel_stats.csv")
@@ -26,7 +27,10 @@ for name in ("bench.json", "bench_under_rocprof.json"):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc_*/*/*counter_collection.csv")):
+for pdir in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    f = one(os.path.relpath(pdir, src) + "/*/*counter_collection.csv") if os.path.isdir(pdir) else None
+    if not f:
+        continue
     for r in csv.DictReader(open(f)):
         counters[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {k: {c: {"per_launch_median": sorted(v)[len(v) // 2], "launches": len(v)} for c, v in d.items()}
