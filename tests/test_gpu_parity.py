@@ -854,6 +854,31 @@ def test_graph_of_32_frames_and_mixed_eager_replay(tr):
             assert torch.equal(got.view(torch.int32), want5.view(torch.int32)), step
     finally:
         tr.enable_stats(False)
+    # (2b) the passes either side of the path are capturable too: render -> tonemap -> re-projection in one graph
+    n = 20_000
+    gen = torch.Generator(device=dev).manual_seed(3)
+    cloud = torch.zeros(n, 8, device=dev)
+    cloud[:, :3] = torch.rand(n, 3, device=dev, generator=gen) * 4 - 2
+    cloud[:, 4:7] = torch.rand(n, 3, device=dev, generator=gen)
+    vp = camera.perspective_vk(60, 1.0) @ camera.look_at((0.5, 1.0, 5.0), (0.0, 0.0, 0.0))
+    img, img8, spl = (torch.zeros(H, W, 4, device=dev), torch.zeros(H, W, 4, dtype=torch.uint8, device=dev), torch.zeros(H, W, 4, device=dev))
+    w8, wspl = torch.zeros_like(img8), torch.zeros_like(spl)
+    tr.post_dev(want5.data_ptr(), W * H, 0, w8.data_ptr(), stream=cur.cuda_stream)        # eager references (size the scratch)
+    tr.splat_dev(cloud.data_ptr(), n, vp, W, H, wspl.data_ptr(), stream=cur.cuda_stream)
+    torch.cuda.synchronize()
+    gp = torch.cuda.CUDAGraph()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(gp, stream=side):
+            tr.render_dev(sc, g, pc5, W, H, img.data_ptr(), stream=side.cuda_stream)
+            tr.post_dev(img.data_ptr(), W * H, 0, img8.data_ptr(), stream=side.cuda_stream)
+            tr.splat_dev(cloud.data_ptr(), n, vp, W, H, spl.data_ptr(), stream=side.cuda_stream)
+    cur.wait_stream(side)
+    for _ in range(3):
+        img8.zero_(), spl.zero_()
+        gp.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(img8, w8) and torch.equal(spl.view(torch.int32), wspl.view(torch.int32))
     # (3) a capture that would need a larger scratch (or a toroidal table upload) is refused, not allocated
     from toroidal_ray_tracing_amd.tracer import Tracer, TrtError
     t2 = Tracer(0)
