@@ -188,8 +188,8 @@ int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt
  * on them can be captured into a hipGraph, replayed, and mixed with eager frames in any order (every
  * frame leaves the ctx's tile-list counters as it found them).  A call that would have to grow the
  * scratch, or to upload the tables of a new toroidal-camera frame, while `stream` is being captured
- * returns TRT_E_INVALID instead of allocating inside the capture; growing the scratch later frees the
- * old block, which invalidates graphs captured before.
+ * returns TRT_E_INVALID instead of allocating inside the capture.  Scratch that a later, larger call
+ * replaces stays allocated until trt_destroy, so graphs captured before keep replaying correctly.
  *
  * Rows [row_begin,row_end) only; outputs are indexed relative to the FULL image, so a
  * rank that owns a row band passes pointers to the full-frame buffers (or to buffers

@@ -879,6 +879,18 @@ def test_graph_of_32_frames_and_mixed_eager_replay(tr):
         gp.replay()
     torch.cuda.synchronize()
     assert torch.equal(img8, w8) and torch.equal(spl.view(torch.int32), wspl.view(torch.int32))
+    # (2c) a later, larger eager frame outgrows the ctx's tile lists: the graphs captured before keep replaying on the
+    #      blocks their arguments name (outgrown scratch is retired, not freed, until trt_destroy)
+    Wb = 1024
+    bigger = torch.zeros(Wb, Wb, 4, device=dev)
+    tr.render_dev(sc, camera.baseline_camera(Wb, Wb), pc5, Wb, Wb, bigger.data_ptr(), stream=cur.cuda_stream)
+    torch.cuda.synchronize()
+    for img_ in imgs:
+        img_.zero_()
+    g32.replay()
+    torch.cuda.synchronize()
+    for k, img_ in enumerate(imgs):
+        assert torch.equal(img_.view(torch.int32), (want5 if k % 2 == 0 else want2).view(torch.int32)), k
     # (3) a capture that would need a larger scratch (or a toroidal table upload) is refused, not allocated
     from toroidal_ray_tracing_amd.tracer import Tracer, TrtError
     t2 = Tracer(0)

@@ -61,6 +61,7 @@ struct trt_ctx {
   DevBuf d_keys;   // depth|index keys of trt_splat_dev (one-pass form)
   DevBuf d_bins;   // … binned form: per-bin count / offset / cursor words (count zero between calls)
   DevBuf d_recs;   // … binned form: point records sorted by bin
+  std::vector<void*> retired;   // scratch blocks replaced by larger ones: a hipGraph captured earlier may still use them
 };
 
 namespace {
@@ -96,18 +97,19 @@ bool capturing(hipStream_t st)
   return cap == hipStreamCaptureStatusActive;
 }
 
-// Grow-only scratch.  Growing frees the old block: a hipGraph captured earlier still holds the old
-// address (include/trt.h: size the ctx with an eager call first), and hipFree/hipMalloc are illegal
-// while `st` is being captured — then the call is refused instead.
 constexpr size_t kSplatBinWordsAlloc = 8192;   // = kSplatMaxBins of trt_kernels.hip
 
+// Grow-only scratch.  A block that is replaced by a larger one is RETIRED, not freed, until trt_destroy: a hipGraph
+// captured earlier keeps replaying on the old block (its kernel arguments hold the old address and capacity), and
+// work still in flight on another stream may be using it.  hipMalloc is illegal while `st` is being captured — then
+// the call is refused instead (include/trt.h: size the ctx with an eager call first).
 int grow(trt_ctx* ctx, DevBuf& b, size_t bytes, hipStream_t st = nullptr)
 {
   if(bytes <= b.cap) return TRT_OK;
   if(capturing(st))
     return fail(ctx, TRT_E_INVALID, "the ctx's scratch would have to grow (%zu -> %zu bytes) while the stream is being "
                 "captured into a hipGraph: make one eager call with the same sizes first", b.cap, bytes);
-  if(b.p) TRT_HIP(ctx, hipFree(b.p));
+  if(b.p) ctx->retired.push_back(b.p);
   b.p = nullptr;
   b.cap = 0;
   TRT_HIP(ctx, hipMalloc(&b.p, bytes));
@@ -333,6 +335,7 @@ extern "C" void trt_destroy(trt_ctx* ctx)
     if(b.p) (void)hipFree(b.p);
   for(DevBuf& b : ctx->d_out)
     if(b.p) (void)hipFree(b.p);
+  for(void* q : ctx->retired) (void)hipFree(q);
   delete ctx;
 }
 
