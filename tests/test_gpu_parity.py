@@ -728,7 +728,7 @@ def test_unaligned_hit_streams(tr, variant):
 def test_frame_sequences_keep_no_state(oracle):
     """One ctx, 40 frames in a row that change size, camera model, scene, kernel variant, solver and
     depth at random: every frame must equal the oracle's — nothing (tile lists, their
-    double-buffered counters, the cached toroidal tables, grow-only scratch) may leak from one
+    tile-list counters, the cached toroidal tables, grow-only scratch) may leak from one
     frame into the next."""
     from toroidal_ray_tracing_amd.tracer import Tracer
     rng = np.random.default_rng(4242)
