@@ -548,12 +548,11 @@ __device__ __forceinline__ bool tile_is_clear(const SceneK& S, const RenderArgs&
 }
 
 // End of a classification block.  The list lengths are accumulated in a.counters[0..1] (zero when the
-// kernel starts); every block takes a ticket on a.counters[2] once its two reservations have
+// kernel starts); every block takes a ticket (sharded: see below) once its two reservations have
 // returned, and the block that draws the LAST ticket — every other block's additions are then
 // performed — moves the totals to a.counts (what the render kernels read) and leaves all three
 // accumulators zero for the next frame.  A frame therefore depends on no other frame: no memset, no
-// double buffering, nothing that distinguishes eager launches from hipGraph replays.  One returning
-// atomic per block (256 blocks at 4096²).
+// double buffering, nothing that distinguishes eager launches from hipGraph replays.
 // The ticket is drawn right after the barrier that follows the reservations and BEFORE the block's list
 // writes (classify_ticket), so that the latency of the returning atomic hides behind those stores; the
 // publication itself (classify_publish) comes last.  (The list entries are read by the NEXT kernel: the

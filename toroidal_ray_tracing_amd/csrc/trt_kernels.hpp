@@ -26,7 +26,7 @@ struct RenderArgs {
   trt_rendered_data* rendered;  // AoS, x*H+y                     (BEF rgen:72-73,111-112)
   unsigned long long* stats;    // [4]: primary, bounce, shadow tests, pixels (optional)
   // tile lists built by tile_classify*_kernel (packed tx | ty << 16 [| miss flag])
-  unsigned int*       counters;     // accumulators of the classification: [0] LIVE, [1] CLEAR, [2] blocks done.
+  unsigned int*       counters;     // accumulators of the classification: [0] LIVE, [1] CLEAR, [2] shards done, [8..15] blocks done per shard.
                                     // Zero between frames: the LAST classification block of a frame publishes the
                                     // totals to `counts` and resets them (no memset, no double buffering: a frame
                                     // depends on no other frame, eager or replayed from a hipGraph)
