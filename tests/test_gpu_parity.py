@@ -565,11 +565,17 @@ def test_tiled_render_matches_full(tr, variant, parts, group, scene_cam):
             assert tr.tiling_rows(tiling, H) == H // parts
             tr.render_tiled_dev(sc, g, pc, W, H, tiling, gathered[p].data_ptr(), camera=cam,
                                 hit_ptrs={"t": t_parts[p].data_ptr()}, stream=s)
-        # non-compact: parts write straight into one full-frame buffer
+        # non-compact: parts write straight into one full-frame buffer — and into one RenderedData buffer (x*H + y:
+        # always full-frame; with groups that are not whole 8-row tile bands the tiles of a part are not contiguous rows)
         direct = torch.zeros(H, W, 4, device=dev)
+        rd_parts = torch.zeros(W * H, 16, device=dev)
         for p in range(parts):
-            tr.render_tiled_dev(sc, g, pc, W, H, abi.trt_tiling(group, parts, p, 0), direct.data_ptr(), camera=cam, stream=s)
+            tr.render_tiled_dev(sc, g, pc, W, H, abi.trt_tiling(group, parts, p, 0), direct.data_ptr(), camera=cam,
+                                rendered_ptr=rd_parts.data_ptr(), stream=s)
+        rd_full = torch.zeros(W * H, 16, device=dev)
+        tr.render_dev(sc, g, pc, W, H, 0, camera=cam, rendered_ptr=rd_full.data_ptr(), stream=s)
         torch.cuda.synchronize()
+        assert torch.equal(rd_parts.view(torch.int32), rd_full.view(torch.int32))
     finally:
         tr.set_render_variant("listed")
     assert torch.equal(trtd.deinterleave(gathered, H, W, group, parts), full)
