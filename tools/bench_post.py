@@ -16,7 +16,7 @@ def t(fn, reps=20, rounds=5):
         e1.record(s); torch.cuda.synchronize()
         if r: out.append(e0.elapsed_time(e1) / reps)
     return statistics.median(out)
-for b in (4, 8, 16, 32, 64, 128, 256):
+for b in ([int(x) for x in sys.argv[1:]] or (4, 8, 16, 32, 64, 128, 256)):   # 0 = the launcher's default
     os.environ["TRT_POST_BLOCKS_PER_CU"] = str(b); _tuning.reload(tr)
     a = t(lambda: tr.post_dev(img.data_ptr(), n, 0, o8.data_ptr(), stream=s.cuda_stream))
     c = t(lambda: tr.post_dev(img.data_ptr(), n, of.data_ptr(), 0, stream=s.cuda_stream))

@@ -12,6 +12,8 @@ from toroidal_ray_tracing_amd.tracer import Tracer
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 cases = set(sys.argv[2:]) or {"c3", "parts", "c4", "trace", "capture", "splat", "persist"}
 dev = torch.device("cuda:0"); tr = Tracer(0); s = torch.cuda.current_stream()
+V = os.environ.get("VARIANT", "listed")   # VARIANT=persistent|static: every render case with that variant
+tr.set_render_variant(V)
 
 
 def timeit(fn, rounds=7, reps=20):
@@ -56,7 +58,7 @@ if "c5" in cases:
 if "persist" in cases:
     tr.set_render_variant("persistent")
     show("C3 persistent variant", timeit(lambda: tr.render_dev(sc1, g, pc, W, W, rgba.data_ptr(), hit_ptrs=hp, stream=s.cuda_stream)), 44 * W * W)
-    tr.set_render_variant("listed")
+    tr.set_render_variant(V)
 if "c4" in cases:
     sc8 = camera.nested_tori_scene()
     tr.set_solver(abi.TRT_SOLVE_F64)

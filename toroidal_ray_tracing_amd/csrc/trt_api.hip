@@ -349,6 +349,16 @@ extern "C" int trt_debug_reload_tuning(trt_ctx* ctx)
 }
 #endif
 
+#ifdef TRT_TIMELINE
+// tools/timeline.py only: a device buffer of [waves of the listed kernel][8] uint64 the kernel stamps (nullptr = off)
+namespace trt { hipError_t set_timeline(void* dev_ptr); }
+extern "C" int trt_debug_set_timeline(trt_ctx* ctx, void* dev_ptr)
+{
+  if(!ctx) return TRT_E_INVALID;
+  return trt::set_timeline(dev_ptr) == hipSuccess ? TRT_OK : TRT_E_HIP;
+}
+#endif
+
 extern "C" int trt_set_solver(trt_ctx* ctx, int precision)
 {
   if(!ctx) return TRT_E_INVALID;

@@ -45,6 +45,15 @@ __device__ __forceinline__ void st4(int32_t* p, int x, int y, int z, int w) { *(
 __device__ __forceinline__ void st4c(float* p, float4 v) { __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, (gptr<f4v>)p); }
 __device__ __forceinline__ void st4c(int32_t* p, int x, int y, int z, int w) { __builtin_nontemporal_store(i4v{x, y, z, w}, (gptr<i4v>)p); }
 #endif
+// -DTRT_TIMELINE (tools/timeline.py only): every wave of the listed kernel stamps the 100-MHz wall clock at entry, before
+// its first tile and at exit, plus the hardware slot it ran in and its first LIVE tile, into g_timeline[wave][8].
+#ifdef TRT_TIMELINE
+__device__ unsigned long long* g_timeline = nullptr;
+#define TRT_STAMP(k, v) do { if(g_timeline && (threadIdx.x & 63) == 0) g_timeline[(size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = (v); } while(0)
+#else
+#define TRT_STAMP(k, v) do { } while(0)
+#endif
+
 __device__ __forceinline__ uint32_t ld1(const uint32_t* base, size_t i) { return ((gptr<const uint32_t>)base)[i]; }
 
 // ------------------------------------------------------------------------------------------
@@ -275,11 +284,7 @@ struct RdSink {
 };
 
 // Writes the wave's LDS image of tile (tx, ty) to RenderedData, transposed (see above).
-#ifdef TRT_NT_RD   // timing builds
-#define st4r st4c
-#else
-#define st4r st4
-#endif
+// Non-temporal like the CLEAR fills (whole 512-B runs, read by nobody in the frame): capture 0.186 → 0.178 ms.
 __device__ __forceinline__ void rd_flush(const RenderArgs& a, const float4* tile, uint32_t tx, uint32_t ty, uint32_t lane)
 {
   __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the reads below see the records
@@ -291,7 +296,7 @@ __device__ __forceinline__ void rd_flush(const RenderArgs& a, const float4* tile
     if(x < a.W && ly < a.n_local_rows)
     {
       const float4 v = tile[rd_unit(xl, yl, k)];
-      st4r(reinterpret_cast<float*>(&a.rendered[(size_t)x * a.H + image_row(a, ly)]) + 4 * k, v);
+      st4c(reinterpret_cast<float*>(&a.rendered[(size_t)x * a.H + image_row(a, ly)]) + 4 * k, v);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -1128,6 +1133,8 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
   __shared__ RenderArgs A_lds;
   __shared__ float4     rd_images[RD ? 4 : 1][RD ? 256 : 1];
   float4* const rd_tile = RD ? rd_images[threadIdx.x >> 6] : nullptr;
+  TRT_STAMP(0, wall_clock64());
+  TRT_STAMP(3, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32));   // HW_ID, XCC_ID
   stage_args(&A_lds, a_arg);
   stage_scene(&S, scene);
   const RenderArgs& a = A_lds;
@@ -1159,6 +1166,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
       live_cache  = i + lane < my_live ? ld1(a.tiles_live, g_wave + (size_t)(i + lane) * n_waves) : 0u;
       clear_cache = i + lane < my_clear ? ld1(a.tiles_clear, g_wave + (size_t)(i + lane) * n_waves) : 0u;
       settle_loads(live_cache, clear_cache);
+      if(i == 0) TRT_STAMP(1, wall_clock64());
     }
     // lane-derived values (lane & 7, lane >> 3, …) are recomputed per trip from an opaque copy:
     // hoisted out of the loop they would be spilled, and a spill reload is a vector-memory load
@@ -1175,6 +1183,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     if(i < my_live && !TRT_SKIP(a, 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
+      if(i == 0) TRT_STAMP(4, 0x100000000ull | packed);
       const uint32_t x = tile_x(packed) * 8 + (ln & 7), ly = tile_y(packed) * 8 + (ln >> 3);
       if(RD && (packed & kTileMissFlag))
         rd_miss_tile(a, rd_tile, tile_x(packed), tile_y(packed), ln);
@@ -1210,6 +1219,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
       n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane) * (uint32_t)S.n_tori;
     }
 #endif
+  TRT_STAMP(2, wall_clock64());
   if(STATS && a.stats)   // STATS = false: the counters are dead code (their VGPRs and increments vanish)
   {
     block_add_stats(a.stats, n_primary, n_bounce, n_shadow, wc);
@@ -1225,11 +1235,7 @@ __device__ __forceinline__ void post_pixel(float4 c, uint64_t i, float4* __restr
   // exp2_poly(0) = 1): when the whole wave sees alpha 1 the fourth pow is skipped
   const float ow = __all(c.w == 1.0f) ? 1.0f : post_gamma(c.w);
   const float4 o = make_float4(post_gamma(c.x), post_gamma(c.y), post_gamma(c.z), ow);
-#ifdef TRT_NT_POST
-  if(f32_out) __builtin_nontemporal_store(f4v{o.x, o.y, o.z, o.w}, (gptr<f4v>)f32_out + i);
-#else
   if(f32_out) f32_out[i] = o;
-#endif
   if(u8_out)
   {
     // UNORM8: round-to-nearest-even of clamp(o, 0, 1)·255 (v_rndne via rintf), R in the low byte
@@ -1237,23 +1243,12 @@ __device__ __forceinline__ void post_pixel(float4 c, uint64_t i, float4* __restr
     const uint32_t g = (uint32_t)rintf(min_(max_(o.y, 0.0f), 1.0f) * 255.0f);
     const uint32_t b = (uint32_t)rintf(min_(max_(o.z, 0.0f), 1.0f) * 255.0f);
     const uint32_t a = (uint32_t)rintf(min_(max_(o.w, 0.0f), 1.0f) * 255.0f);
-#ifdef TRT_NT_POST
-    __builtin_nontemporal_store(r | (g << 8) | (b << 16) | (a << 24), (gptr<uint32_t>)u8_out + i);
-#else
     u8_out[i] = r | (g << 8) | (b << 16) | (a << 24);
-#endif
   }
 }
 
-#ifdef TRT_NT_POST
-__device__ __forceinline__ float4 ldp(const float4* in, uint64_t i)
-{
-  const f4v v = __builtin_nontemporal_load((gptr<f4v>)const_cast<float4*>(in) + i);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-#else
-__device__ __forceinline__ float4 ldp(const float4* in, uint64_t i) { return in[i]; }
-#endif
+// (Non-temporal loads and stores here: within noise, 0.088 against 0.089 ms — the → rgba8 pass is bound by the ≈200
+// VALU instructions per pixel of the exact-operation pow, → f32 takes the same time with 1.6× the bytes.)
 // Four pixels per lane and trip, their loads issued together: with one 16-B load in flight per
 // lane the pass was bound by memory latency (32 KB in flight per CU ≈ 2.8 TB/s of reads), not by
 // the ≈55 VALU instructions per channel.
@@ -1264,14 +1259,14 @@ __global__ __launch_bounds__(256) void post_kernel(const float4* __restrict__ in
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for(; i + 3 * stride < n; i += 4 * stride)
   {
-    const float4 c0 = ldp(in, i), c1 = ldp(in, i + stride), c2 = ldp(in, i + 2 * stride), c3 = ldp(in, i + 3 * stride);
+    const float4 c0 = in[i], c1 = in[i + stride], c2 = in[i + 2 * stride], c3 = in[i + 3 * stride];
     post_pixel(c0, i, f32_out, u8_out);
     post_pixel(c1, i + stride, f32_out, u8_out);
     post_pixel(c2, i + 2 * stride, f32_out, u8_out);
     post_pixel(c3, i + 3 * stride, f32_out, u8_out);
   }
   for(; i < n; i += stride)
-    post_pixel(ldp(in, i), i, f32_out, u8_out);
+    post_pixel(in[i], i, f32_out, u8_out);
 }
 
 hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, const Tuning& tn,
@@ -1630,6 +1625,14 @@ hipError_t launch_zero_words(unsigned int* words, uint32_t n, hipStream_t stream
   hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, stream, words, n);
   return hipGetLastError();
 }
+
+#ifdef TRT_TIMELINE
+hipError_t set_timeline(void* dev_ptr)
+{
+  unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &p, sizeof(p));
+}
+#endif
 
 Tuning tuning_from_env()
 {
