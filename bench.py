@@ -55,11 +55,11 @@ BYTES_PER_PIXEL_CAPTURE = 44 + 64   # + RenderedData AoS (BEF/shaders/host_devic
 # Algorithmic FLOPs of the intersection rows T1/T2, counted from
 # toroidal_ray_tracing_amd/csrc/trt_device.hpp with fma = 2, every other + - * / sqrt = 1:
 #   every traced test   TorusTest::setup up to the sphere cull: e = o - c (3), n (5), tc (1), q (6), m (5)      = 20
-#   every solved test   rest of setup: U (3), window (4), a b c (9), cylinder clip (4 + 2 + 6), slab clip (9),
-#                       kappa A4 P2 Q1 S0 (11), k6 w (4) = 52;  finish(): P (6), rho (4), e g s gh (12), du t (5) = 27  = 79
+#   every solved test   rest of setup: U (3), window (4), a b c (9), slab clip (9), kappa A4 P2 Q1 S0 (11),
+#                       k6 w (4) = 40;  finish(): P (6), rho (4), e g s gh (12), du t (5) = 27                      = 67
 #   every evaluation    step(): f (7), f' (5), f/f' and u - f/f' (2)                                             = 14
 # Ray generation, shading and the normal are NOT counted (they add < 10 % on the baseline frame).
-FLOP_PER_TRACED, FLOP_PER_SOLVED, FLOP_PER_EVAL = 20, 79, 14
+FLOP_PER_TRACED, FLOP_PER_SOLVED, FLOP_PER_EVAL = 20, 67, 14
 
 
 def parse():

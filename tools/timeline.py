@@ -47,7 +47,8 @@ print(f"{case}: {n} waves stamped; kernel span (first wave in → last wave out)
 has_tile = t1 != 0
 pro = (np.where(has_tile, t1, t2) - t0) * tick
 body = (t2 - np.where(has_tile, t1, t2)) * tick
-for nm, v in (("prologue (entry → lists settled)", pro), ("tiles (→ exit)", body[has_tile]), ("whole wave", (t2 - t0) * tick)):
+stg = (t[:, 5] - t0) * tick
+for nm, v in (("staging (entry → past the barrier)", stg), ("prologue (entry → lists settled)", pro), ("tiles (→ exit)", body[has_tile]), ("whole wave", (t2 - t0) * tick)):
     q = np.percentile(v, [10, 50, 90, 99, 100])
     print(f"  {nm:36s} mean {v.mean():6.2f}  p10 {q[0]:6.2f}  p50 {q[1]:6.2f}  p90 {q[2]:6.2f}  p99 {q[3]:6.2f}  max {q[4]:6.2f} us   (sum {v.sum() / 1e3:.1f} wave-ms)")
 # waves in flight over time

@@ -45,8 +45,8 @@ __device__ __forceinline__ void st4(int32_t* p, int x, int y, int z, int w) { *(
 __device__ __forceinline__ void st4c(float* p, float4 v) { __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, (gptr<f4v>)p); }
 __device__ __forceinline__ void st4c(int32_t* p, int x, int y, int z, int w) { __builtin_nontemporal_store(i4v{x, y, z, w}, (gptr<i4v>)p); }
 #endif
-// -DTRT_TIMELINE (tools/timeline.py only): every wave of the listed kernel stamps the 100-MHz wall clock at entry, before
-// its first tile and at exit, plus the hardware slot it ran in and its first LIVE tile, into g_timeline[wave][8].
+// -DTRT_TIMELINE (tools/timeline.py only): every wave of the listed kernel stamps the 100-MHz wall clock at entry, past the staging barrier,
+// before its first tile and at exit, plus the hardware slot it ran in and its first LIVE tile, into g_timeline[wave][8].
 #ifdef TRT_TIMELINE
 __device__ unsigned long long* g_timeline = nullptr;
 #define TRT_STAMP(k, v) do { if(g_timeline && (threadIdx.x & 63) == 0) g_timeline[(size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = (v); } while(0)
@@ -1137,6 +1137,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
   TRT_STAMP(3, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32));   // HW_ID, XCC_ID
   stage_args(&A_lds, a_arg);
   stage_scene(&S, scene);
+  TRT_STAMP(5, wall_clock64());
   const RenderArgs& a = A_lds;
   const uint32_t lane    = threadIdx.x & 63;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
