@@ -43,11 +43,11 @@ t = t[used]; n = len(t)
 t0, t1, t2, hw = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
 base = t0.min(); tick = 0.01   # µs per tick (100 MHz)
 span = (t2.max() - base) * tick
-print(f"{case}: {n} waves stamped; kernel span (first wave in → last wave out) {span:.1f} us; last wave start at {(t0.max() - base) * tick:.1f} us")
+print(f"{case}: {n} waves stamped, {(t[:, 5] == 0).sum()} of them left before staging (their block owns no list entry); kernel span (first wave in → last wave out) {span:.1f} us; last wave start at {(t0.max() - base) * tick:.1f} us")
 has_tile = t1 != 0
 pro = (np.where(has_tile, t1, t2) - t0) * tick
 body = (t2 - np.where(has_tile, t1, t2)) * tick
-stg = (t[:, 5] - t0) * tick
+stg = ((t[:, 5] - t0) * tick)[t[:, 5] != 0]   # (blocks that own no list entry leave before the staging)
 for nm, v in (("staging (entry → past the barrier)", stg), ("prologue (entry → lists settled)", pro), ("tiles (→ exit)", body[has_tile]), ("whole wave", (t2 - t0) * tick)):
     q = np.percentile(v, [10, 50, 90, 99, 100])
     print(f"  {nm:36s} mean {v.mean():6.2f}  p10 {q[0]:6.2f}  p50 {q[1]:6.2f}  p90 {q[2]:6.2f}  p99 {q[3]:6.2f}  max {q[4]:6.2f} us   (sum {v.sum() / 1e3:.1f} wave-ms)")

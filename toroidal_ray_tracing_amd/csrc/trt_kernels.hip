@@ -54,6 +54,7 @@ __device__ unsigned long long* g_timeline = nullptr;
 #define TRT_STAMP(k, v) do { } while(0)
 #endif
 
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }   // (min(int, uint32_t) resolves to the double overload)
 __device__ __forceinline__ uint32_t ld1(const uint32_t* base, size_t i) { return ((gptr<const uint32_t>)base)[i]; }
 
 // ------------------------------------------------------------------------------------------
@@ -208,6 +209,34 @@ __device__ __forceinline__ void stage_args(RenderArgs* lds, const RenderArgs& ar
   uint32_t*       dst = reinterpret_cast<uint32_t*>(lds);
   for(uint32_t i = threadIdx.x; i < sizeof(RenderArgs) / 4; i += blockDim.x)
     dst[i] = src[i];
+}
+
+// Both stagings in ONE pass for a block of exactly 256 threads: thread t < sizeof(RenderArgs)/4 copies argument dword t,
+// the threads from 128 on copy the scene records in use — one load per thread and one barrier.  (The general loops above
+// compile to ≈200 instructions per wave with an unknown block size; a wave of the listed kernel lives for one tile, so
+// its prologue was 40 % of all instructions the LIVE part of config 3 issued — tools/timeline.py)
+__device__ __forceinline__ void stage_block256(SceneK* S, RenderArgs* A, const SceneK& scene, const RenderArgs& arg)
+{
+  constexpr uint32_t NA = sizeof(RenderArgs) / 4;
+  static_assert(NA <= 128 && sizeof(RenderArgs) % 4 == 0, "RenderArgs must fit the lower half of the block");
+  const uint32_t tid = threadIdx.x;
+  if(tid < NA)
+    reinterpret_cast<uint32_t*>(A)[tid] = reinterpret_cast<const uint32_t*>(&arg)[tid];
+  else if(tid >= 128u)
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&scene);
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(S);
+    const uint32_t  n = (uint32_t)scene.n_tori, nm = (uint32_t)scene.n_mat;
+    const uint32_t  c0 = 12, c1 = c0 + (scene.f64 ? 0u : 10u * n), c2 = c1 + (scene.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
+                   c4 = c3 + 11u * nm;
+#pragma unroll 1
+    for(uint32_t i = tid - 128u; i < c4; i += 128u)
+    {
+      const uint32_t off = i < c0 ? i : i < c1 ? 12u + (i - c0) : i < c2 ? 92u + (i - c1) : i < c3 ? 252u + (i - c2) : 292u + (i - c3);
+      dst[off] = src[off];
+    }
+  }
+  __syncthreads();
 }
 
 constexpr float kTMin = 0.001f;    // rgen:51, rchit:114
@@ -837,8 +866,8 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   // list lengths as published by the classification, never beyond the lists' capacity
-  const uint32_t n_live  = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)0)), a.cap_live);
-  const uint32_t n_clear = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)1)), a.cap_clear);
+  const uint32_t n_live  = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)0)), a.cap_live);
+  const uint32_t n_clear = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)1)), a.cap_clear);
 
   // Queue state.  Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k caches the
   // wave's k-th entry of the current batch of 64 (one gather load per 64 tiles) and entries
@@ -1115,6 +1144,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
 #else
 #define TRT_SKIP(a, bit) false
 #endif
+constexpr uint32_t kListedThreads = 256;   // block size of the listed kernel: stage_block256() and the launcher rely on it
 #ifndef TRT_LISTED_WAVES
 #define TRT_LISTED_WAVES 6
 #endif
@@ -1135,16 +1165,22 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
   float4* const rd_tile = RD ? rd_images[threadIdx.x >> 6] : nullptr;
   TRT_STAMP(0, wall_clock64());
   TRT_STAMP(3, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32));   // HW_ID, XCC_ID
-  stage_args(&A_lds, a_arg);
-  stage_scene(&S, scene);
+  // list lengths as published by the classification, never beyond the lists' capacity; read through the kernel
+  // arguments BEFORE anything is staged: a block none of whose waves owns an entry leaves at once (the grid is sized
+  // for the worst case, one wave per four tiles; ≈15 % of the baseline frame's blocks own nothing)
+  const uint32_t n_live  = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a_arg.counts, (size_t)0)), a_arg.cap_live);
+  const uint32_t n_clear = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a_arg.counts, (size_t)1)), a_arg.cap_clear);
+  if(blockIdx.x * (kListedThreads / 64u) >= (n_live > n_clear ? n_live : n_clear))
+  {
+    TRT_STAMP(2, wall_clock64());
+    return;
+  }
+  stage_block256(&S, &A_lds, scene, a_arg);
   TRT_STAMP(5, wall_clock64());
   const RenderArgs& a = A_lds;
   const uint32_t lane    = threadIdx.x & 63;
-  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-  const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  // list lengths as published by the classification, never beyond the lists' capacity
-  const uint32_t n_live  = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)0)), a.cap_live);
-  const uint32_t n_clear = min(__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)1)), a.cap_clear);
+  const uint32_t n_waves = gridDim.x * (kListedThreads / 64u);
+  const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (kListedThreads / 64u) + (threadIdx.x >> 6));
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
   WorkCount wc;
 
@@ -1156,16 +1192,20 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
   // Measured alternatives (4096², one process, interleaved rounds): dealing the CLEAR entries
   // only over the waves that own a LIVE tile (no store-only tail of the grid) +21 %; tracing
   // first and clearing afterwards +5 %, on odd waves only +4 %, on odd blocks only +2 %.
-  const uint32_t my_live  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;
-  const uint32_t my_clear = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
-  const uint32_t n_iter = my_live > my_clear ? my_live : my_clear;
+  // (entry i of this wave is list entry g_wave + i·n_waves: owned while that index is below the list's length —
+  // compared, not divided: the two integer divisions for the entry counts were 70 instructions of every wave)
   uint32_t live_cache = 0, clear_cache = 0;
-  for(uint32_t i = 0; i < n_iter; ++i)
+  for(uint32_t i = 0;; ++i)
   {
+    const uint32_t entry = g_wave + i * n_waves;   // < 2^32: the lists hold fewer than 2^31 entries and n_waves <= their capacity
+    const bool own_live = entry < n_live, own_clear = entry < n_clear;
+    if(!own_live && !own_clear)
+      break;
     if((i & 63u) == 0)
     {
-      live_cache  = i + lane < my_live ? ld1(a.tiles_live, g_wave + (size_t)(i + lane) * n_waves) : 0u;
-      clear_cache = i + lane < my_clear ? ld1(a.tiles_clear, g_wave + (size_t)(i + lane) * n_waves) : 0u;
+      const uint64_t e = entry + (uint64_t)lane * n_waves;
+      live_cache  = e < n_live ? ld1(a.tiles_live, (size_t)e) : 0u;
+      clear_cache = e < n_clear ? ld1(a.tiles_clear, (size_t)e) : 0u;
       settle_loads(live_cache, clear_cache);
       if(i == 0) TRT_STAMP(1, wall_clock64());
     }
@@ -1173,7 +1213,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     // hoisted out of the loop they would be spilled, and a spill reload is a vector-memory load
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
-    if(i < my_clear && !TRT_SKIP(a, 1u) && !TRT_SKIP(a, 4u))
+    if(own_clear && !TRT_SKIP(a, 1u))
     {
       const uint32_t cpacked = __builtin_amdgcn_readlane(clear_cache, i & 63u);
       n_primary += clear_macro(a, cpacked, ln) * (uint32_t)S.n_tori;
@@ -1181,7 +1221,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
         for(uint32_t j = 0; j < kMacroTiles; ++j)
           rd_miss_tile(a, rd_tile, tile_x(cpacked) + j, tile_y(cpacked), ln);
     }
-    if(i < my_live && !TRT_SKIP(a, 2u))
+    if(own_live && !TRT_SKIP(a, 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
       if(i == 0) TRT_STAMP(4, 0x100000000ull | packed);
@@ -1208,18 +1248,6 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
         rd_flush(a, rd_tile, tile_x(packed), tile_y(packed), ln);
     }
   }
-#ifdef TRT_TUNING
-  if(a.debug_skip & 4u)   // experiment: all clear tiles after the traced ones
-    for(uint32_t i = 0; i < my_clear; ++i)
-    {
-      if((i & 63u) == 0)
-      {
-        clear_cache = i + lane < my_clear ? ld1(a.tiles_clear, g_wave + (size_t)(i + lane) * n_waves) : 0u;
-        settle_loads(live_cache, clear_cache);
-      }
-      n_primary += clear_macro(a, __builtin_amdgcn_readlane(clear_cache, i & 63u), lane) * (uint32_t)S.n_tori;
-    }
-#endif
   TRT_STAMP(2, wall_clock64());
   if(STATS && a.stats)   // STATS = false: the counters are dead code (their VGPRs and increments vanish)
   {
@@ -1649,7 +1677,6 @@ Tuning tuning_from_env()
   if(getenv("TRT_DEBUG_TILES")) t.debug_tiles = 1;
   u64("TRT_PERSIST_BLOCKS", t.persist_blocks);
   u64("TRT_LISTED_BLOCKS", t.listed_blocks);
-  u32("TRT_LISTED_THREADS", t.listed_threads);
   i32("TRT_TILE", t.static_tile);
   u64("TRT_TRACE_BLOCKS", t.trace_blocks);
   u64("TRT_POST_BLOCKS_PER_CU", t.post_blocks_per_cu);
@@ -1688,9 +1715,7 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       // (measured optimum at 2048², 4096² and 8192²; 8,192 blocks cost +25 % at 4096²)
       uint64_t lcap = tiles / 16 > (uint64_t)n_cus * 4 ? tiles / 16 : (uint64_t)n_cus * 4;
       if(tn.listed_blocks) lcap = tn.listed_blocks;
-      uint32_t bthreads = tn.listed_threads;
-      if(bthreads != 64 && bthreads != 128) bthreads = 256;   // __launch_bounds__(256): nothing larger may be launched
-      const uint32_t wpb = bthreads / 64;
+      constexpr uint32_t bthreads = kListedThreads, wpb = bthreads / 64;   // the kernel's staging assumes 256-thread blocks (64 / 128: measured slower)
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
 #define TRT_LAUNCH_LISTED(REAL, DK_)                                                                                   \
   do {                                                                                                                 \

@@ -52,7 +52,6 @@ struct Tuning {
   int      debug_tiles        = 0;    // TRT_DEBUG_TILES: print the list lengths after every frame (synchronises)
   uint64_t persist_blocks     = 0;    // TRT_PERSIST_BLOCKS   (0 = default)
   uint64_t listed_blocks      = 0;    // TRT_LISTED_BLOCKS
-  uint32_t listed_threads     = 256;  // TRT_LISTED_THREADS
   int      static_tile        = 8;    // TRT_TILE
   uint64_t trace_blocks       = 0;    // TRT_TRACE_BLOCKS
   uint64_t post_blocks_per_cu = 0;    // TRT_POST_BLOCKS_PER_CU
