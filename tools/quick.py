@@ -42,6 +42,17 @@ hp = {k: v.data_ptr() for k, v in hits.items()}
 sc1, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5)
 if "c3" in cases:
     show("C3 4096^2 listed", timeit(lambda: tr.render_dev(sc1, g, pc, W, W, rgba.data_ptr(), hit_ptrs=hp, stream=s.cuda_stream)), 44 * W * W)
+if "c3alt" in cases:
+    # the same frame into FOUR alternating output sets (3 GB): nothing a frame writes can still sit in the 256-MB Infinity Cache
+    # when the next frame writes the same addresses — what the memory side of the frame costs without that reuse
+    sets = [(torch.empty(W, W, 4, device=dev), {k: torch.empty(W * W, device=dev) for k in hits}) for _ in range(4)]
+    ptrs = [(r.data_ptr(), {k: v.data_ptr() for k, v in h.items()}) for r, h in sets]
+    state = {"i": 0}
+    def alt():
+        r, h = ptrs[state["i"] & 3]; state["i"] += 1
+        tr.render_dev(sc1, g, pc, W, W, r, hit_ptrs=h, stream=s.cuda_stream)
+    show("C3 into 4 alternating output sets", timeit(alt), 44 * W * W)
+    del sets
 if "parts" in cases:
     for skip, nm in ((1, "C3 LIVE part alone (CLEAR skipped)"), (2, "C3 CLEAR part alone (LIVE skipped)")):
         os.environ["TRT_DEBUG_SKIP"] = str(skip); _tuning.reload(tr)
