@@ -2,7 +2,7 @@
 """Per-wave timeline of the listed render kernel (GPU box).  Needs the -DTRT_TIMELINE build:
     make -C toroidal_ray_tracing_amd/csrc timeline        (-> toroidal_ray_tracing_amd/libtrt_timeline.so)
 Every wave stamps the 100-MHz wall clock at entry (t0), before its first tile (t1) and at exit (t2) plus HW_ID / XCC_ID.
-usage: timeline.py [c3|c3live|c4|c4f32|toro]   — c3live = config 3 with the CLEAR tiles skipped (TRT_DEBUG_SKIP=1)
+usage: timeline.py [c3|c3live|c4|c4f32|toro|capture]   — c3live = config 3 with the CLEAR tiles skipped (TRT_DEBUG_SKIP=1)
 Prints: kernel span, ramp (first→last wave start), waves in flight over time, the prologue and tile time distributions,
 and what the kernel would take if the same wave-seconds were spread evenly over the resident slots."""
 import ctypes, os, sys
@@ -25,10 +25,19 @@ if case == "c3live":
 elif case in ("c4", "c4f32"):
     sc = camera.nested_tori_scene()
     if case == "c4": tr.set_solver(abi.TRT_SOLVE_F64)
+rend = None
+if case in ("toro", "capture"):   # the toroidal capture of bench.py / quick.py (4096 x 2048, camera inside an R=6 torus); capture: + RenderedData
+    W, H = 4096, 2048
+    sc = camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC)
+    g, cam = camera.toroidal_camera(W, H), abi.TRT_CAMERA_TOROIDAL
+    pc.rho = 4.0
+    if case == "capture":
+        rend = torch.empty(W * H, 16, device=dev)
 rgba = torch.empty(H, W, 4, device=dev)
 hits = {k: torch.empty(W * H, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
 hp = {k: v.data_ptr() for k, v in hits.items()}
-frame = lambda: tr.render_dev(sc, g, pc, W, H, rgba.data_ptr(), camera=cam, hit_ptrs=hp, stream=s.cuda_stream)
+frame = lambda: tr.render_dev(sc, g, pc, W, H, rgba.data_ptr(), camera=cam, hit_ptrs=hp, stream=s.cuda_stream,
+                              rendered_ptr=rend.data_ptr() if rend is not None else 0)
 for _ in range(20): frame()
 torch.cuda.synchronize()
 NW = 1 << 20   # more than any grid has waves
