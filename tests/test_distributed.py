@@ -140,13 +140,13 @@ def _bench(args, env=None):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("n", [2, 4, 8])
 def test_bench_launcher_starts_the_ranks_itself(n):
     """`python bench.py --gpus 2` (no torchrun around it): the parent spawns 2 ranks, relays rank 0's line, and
     that line says n_gpus 2.  --backend gloo --dry-run is the CPU rehearsal: rank-coded rows instead of rendered
     ones, the REAL TiledFrame gathers, every rank checks the assembled frame."""
     import json
-    p = _bench(["--gpus", str(n), "--backend", "gloo", "--dry-run", "--size", "64"])
+    p = _bench(["--gpus", str(n), "--backend", "gloo", "--dry-run", "--size", "128" if n == 8 else "64"])   # 8 ranks: the job size of config 5
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
