@@ -497,6 +497,12 @@ def worker(a, world, rank, local):
     tflops = flop_frame / (kern_ms * 1e-3) / 1e12
     frac_hbm, frac_valu = achieved / HBM_PEAK_GBPS, tflops / FP32_PEAK_TFLOPS
 
+    # N > 1: the slowest rank's render time per frame — what the sharded path alone delivers (no collective)
+    kmax = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    kern_ms_max = float(kmax.item())
+
     # N > 1, diagnostics only (outside the timed region): the collectives of one frame alone, so that the
     # line shows what binds the step — the rank-local render (roofline.kernel_ms) or replicating the framebuffer
     gather_ms = None
@@ -550,6 +556,9 @@ def worker(a, world, rank, local):
                       "model": f"{FLOP_PER_TRACED}/traced test + {FLOP_PER_SOLVED}/solved test + {FLOP_PER_EVAL}/evaluation of (f,f'); "
                                "fma = 2; ray generation, normals and shading not counted"},
             "gather_ms": gather_ms,
+            # the rank-local renders alone (max over ranks of the HIP-event render time per frame): the part of the path that
+            # shards; `value` above includes replicating the framebuffer on every GPU, as north_star prescribes
+            "render_only_primary_tests_per_s": cnt["primary_tests"] / (kern_ms_max * 1e-3) if world > 1 else None,
             "target_primary_tests_per_s": 2.0e9,
             "roofline": {"bound": "hbm" if frac_hbm >= frac_valu else "mfma", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": frac_hbm, "traffic": traffic,
