@@ -25,12 +25,16 @@ and build + walk a quartic, `traced_tests_per_s` the tests a lane executed at al
 
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (a parent process that makes no GPU
 call runs `torch.distributed.run` and relays rank 0's JSON line); launched BY torch.distributed.run
-(RANK/WORLD_SIZE in the environment) it is one of the ranks.  The SAME 4096² frame is tiled across
-the ranks in interleaved groups of rows and the rgba32f framebuffer is all-gathered over RCCL/xGMI
-inside the timed step, as BASELINE.json north_star prescribes → "scaling": "strong".
+(RANK/WORLD_SIZE in the environment) it is one of the ranks.  The SAME 4096² frames are tiled across
+the ranks in interleaved groups of rows, and the rgba32f framebuffer of the frame that leaves the loop —
+the last frame of every step, as the reference reads its image back once per 60-frame batch
+(BEF/main.cpp:339-343, 384-399) — is all-gathered over RCCL/xGMI inside the timed step, as BASELINE.json
+north_star prescribes → "scaling": "strong".  `--gather-every 1` replicates EVERY frame on every GPU
+(link-bound by two orders of magnitude); `gather_ms` and `render_only_primary_tests_per_s`
+in the N > 1 line say what a gather and the sharded renders cost on their own.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-step F]
-                       [--variant listed|persistent|static] [--gather fp32|rgba8|none]
+                       [--variant listed|persistent|static] [--gather fp32|rgba8|none] [--gather-every step|K]
                        [--no-cpu-baseline] [--no-secondary] [--size 4096] [--depth 5]
 """
 import argparse
@@ -75,7 +79,12 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (N = 1 only)")
     ap.add_argument("--hits", default="tpn", choices=["tpn", "none"], help="first-hit record streams to write")
     ap.add_argument("--gather", default="fp32", choices=["fp32", "rgba8", "none"],
-                    help="N>1: what is all-gathered after each frame (default: the rgba32f framebuffer)")
+                    help="N>1: what is all-gathered (default: the rgba32f framebuffer)")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="one GPU: run the N>1 code path (RCCL group of one rank, forced collectives) — a rehearsal, not a measurement")
+    ap.add_argument("--gather-every", default="step",
+                    help="N>1: gather every K-th frame; 'step' (default) = once per step, the batch's last frame — the reference reads "
+                         "its image back once per 60-frame batch (BEF/main.cpp:339-343,384-399); 1 = replicate every frame")
     ap.add_argument("--group-rows", type=int, default=0, help="N>1: rows per interleaved group (0 = 8 cycles per frame)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU rehearsal of the launcher and the gather (needs --dry-run)")
@@ -377,11 +386,12 @@ def dry_run(a, world, rank):
 
     class _S:
         cuda_stream = 0
+    ge = 2 if a.gather_every == "step" else max(1, int(a.gather_every))   # rehearsal: a "step" of two frames
     frame = trtd.TiledFrame(_PatternTracer(rank), W, H, world, rank, torch.device("cpu"), group_rows=a.group_rows or None,
-                            gather=a.gather if a.gather != "rgba8" else "fp32")
+                            gather=a.gather if a.gather != "rgba8" else "fp32", gather_every=ge)
     ok = True
     if world > 1:
-        for _ in range(3):
+        for _ in range(2 * ge + 1):
             frame.render(None, None, None, 0, _S())
         full = frame.finish()
         G = frame.group_rows
@@ -418,9 +428,18 @@ def worker(a, world, rank, local):
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # --rehearse-collective (one GPU): the code path of N > 1 — RCCL process group, forced collectives, per-frame events,
+    # the all-reduces and the gather diagnostics — in a world of ONE rank; not a measurement of anything multi-GPU
+    multi = world > 1 or a.rehearse_collective
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    elif multi:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     W = H = a.size
     F = max(1, a.frames_per_step)
@@ -433,8 +452,10 @@ def worker(a, world, rank, local):
         tr.set_render_variant(a.variant)
     variant = tr.render_variant()
 
+    gather_every = F if a.gather_every == "step" else max(1, int(a.gather_every))
     frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else (),
-                            gather=a.gather, group_rows=a.group_rows or None)
+                            gather=a.gather, group_rows=a.group_rows or None, gather_every=gather_every,
+                            force_collective=a.rehearse_collective)
     stream = torch.cuda.current_stream()
 
     def one_frame(ev=None):
@@ -449,24 +470,25 @@ def worker(a, world, rank, local):
     tr.enable_stats(False)
     keys = ("primary_tests", "bounce_tests", "shadow_tests", "pixels", "traced_tests", "solved_tests", "evaluations")
     tests = torch.tensor([st[k] for k in keys], dtype=torch.int64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tests)
     cnt = dict(zip(keys, (int(v) for v in tests.tolist())))
     if not os.environ.get("TRT_DEBUG_SKIP"):   # a timing ablation of the tuning build renders part of the frame only
         assert cnt["pixels"] == W * H and cnt["primary_tests"] == W * H * sc.n_tori
 
+    frame.restart()   # the gathers fall on the last frame of every step from here on
     for _ in range(a.warmup):
         for _ in range(F):
             one_frame()
     frame.finish()
     # HIP events on the launch stream (torch's current stream IS the stream handed to trt_render*_dev).
-    # N = 1: one pair around each step's F back-to-back frames; N > 1: a pair around every frame's render
-    # launches, because the stream also carries the waits on the gathers.
-    per_frame = world > 1
+    # One pair around each step's F back-to-back frames; with a gather after EVERY frame (--gather-every 1) a pair around
+    # every frame's render launches instead, because the stream then also carries the waits on the gathers.
+    per_frame = multi and frame.gather and gather_every == 1
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(a.steps * (F if per_frame else 1))]
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -479,12 +501,12 @@ def worker(a, world, rank, local):
             evs[k][1].record(stream)
     frame.finish()   # N > 1: the last frames' all-gathers are part of the K steps
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     n_frames = a.steps * F
@@ -499,14 +521,14 @@ def worker(a, world, rank, local):
 
     # N > 1: the slowest rank's render time per frame — what the sharded path alone delivers (no collective)
     kmax = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     kern_ms_max = float(kmax.item())
 
     # N > 1, diagnostics only (outside the timed region): the collectives of one frame alone, so that the
     # line shows what binds the step — the rank-local render (roofline.kernel_ms) or replicating the framebuffer
     gather_ms = None
-    if world > 1 and frame.gather:
+    if multi and frame.gather:
         try:
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
@@ -556,9 +578,11 @@ def worker(a, world, rank, local):
                       "model": f"{FLOP_PER_TRACED}/traced test + {FLOP_PER_SOLVED}/solved test + {FLOP_PER_EVAL}/evaluation of (f,f'); "
                                "fma = 2; ray generation, normals and shading not counted"},
             "gather_ms": gather_ms,
+            "gather_every_frames": (gather_every if frame.gather else None),
+            "rehearse_collective": bool(a.rehearse_collective),
             # the rank-local renders alone (max over ranks of the HIP-event render time per frame): the part of the path that
             # shards; `value` above includes replicating the framebuffer on every GPU, as north_star prescribes
-            "render_only_primary_tests_per_s": cnt["primary_tests"] / (kern_ms_max * 1e-3) if world > 1 else None,
+            "render_only_primary_tests_per_s": cnt["primary_tests"] / (kern_ms_max * 1e-3) if multi else None,
             "target_primary_tests_per_s": 2.0e9,
             "roofline": {"bound": "hbm" if frac_hbm >= frac_valu else "mfma", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": frac_hbm, "traffic": traffic,
@@ -583,7 +607,7 @@ def worker(a, world, rank, local):
             out["cpu_baseline_1thread"] = cb.pop("one_thread")
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     tr.close()

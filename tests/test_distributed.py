@@ -104,10 +104,18 @@ def _worker(rank, world, port, W, H, G, out):
         for depth in (2, 3):
             frame8.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
         full8 = frame8.finish().clone()
+        # gathers once per batch of two frames: frames 1 and 3 are gathered (maxDepth 2, then 3), frames 0, 2, 4 are not;
+        # the batch's tiling is the balanced one (interleaved groups), and the frame handed out is the last GATHERED one
+        frameb = trtd.TiledFrame(tr, W, H, world, rank, torch.device("cpu"), gather_every=2)
+        assert frameb.group_rows == trtd.default_group_rows(H, world, trtd.DEFAULT_CYCLES) and "every 2 frames" in frameb.describe()
+        for depth in (1, 2, 1, 3, 1):
+            frameb.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
+        fullb = frameb.finish().clone()
         if rank == 0:
             want, _, _, _ = tr.oracle.render(sc, g, camera.baseline_push(3), W, H, want_hits=False)
             ok = bool(np.array_equal(full.numpy(), want))
             ok = ok and full8.dtype == torch.uint8 and bool(np.array_equal(full8.numpy(), tr.oracle.post(want)[1]))
+            ok = ok and bool(np.array_equal(fullb.numpy(), want))
             out.put(ok)
         dist.barrier()
     finally:

@@ -507,6 +507,14 @@ def test_rccl_collective_path_world_1(tr):
                 tr.post_dev(want.data_ptr(), W * H, 0, w8.data_ptr(), stream=stream.cuda_stream)
                 torch.cuda.synchronize()
                 assert full.dtype == torch.uint8 and torch.equal(full, w8)
+        # one gather per batch of three frames (what bench.py --gpus N does per step): frames 2 and 5 are gathered,
+        # the last GATHERED frame is the one handed out
+        frame = trtd.TiledFrame(tr, W, H, 1, 0, dev, gather="fp32", force_collective=True, gather_every=3)
+        for depth in (1, 2, 5, 1, 2, 3, 1):
+            frame.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, stream)
+        full = frame.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(full.view(torch.int32), want.view(torch.int32))
     finally:
         dist.destroy_process_group()
 

@@ -17,6 +17,12 @@ the render, so ONE cycle — plain row bands, one large collecti
 overhead of eight small ones (xGMI is point-to-point, 7 links per GPU; RCCL spreads a large
 collective over all of them); without a gather (`gather="none"`) eight cycles, an interleaving
 fine enough to balance the load (the torus sits in the middle rows).
+
+How often: `gather_every` = F gathers only every F-th frame — the frame that leaves the render loop.  The reference's
+loop renders 60 frames per camera radius and reads the image back once, after the 60th (BEF/main.cpp:339-343 `counter ==
+60 → saveRender`, :384-399 copy + write); replicating every one of them on every GPU would make the step link-bound
+by two orders of magnitude for frames nobody takes off the GPU.  `bench.py --gpus N` gathers once per step
+(= one batch of 64 frames); `gather_every=1` is the per-frame replication.
 """
 import torch
 import torch.distributed as dist
@@ -65,19 +71,24 @@ class TiledFrame:
     """
 
     def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=None,
-                 gather=True, force_collective=False):
+                 gather=True, force_collective=False, gather_every=1):
         """gather: True / "fp32" — all-gather the rgba32f framebuffer (default, what north_star
         prescribes); "rgba8" — tonemap each rank's rows (trt_post_dev, post.frag) and all-gather
         the 8-bit image a swapchain would present: 4x fewer bytes over xGMI, the rgba32f image
         stays sharded; False / "none" — no collective.  force_collective: issue the collective
-        even when world == 1 (exercises the RCCL path on a one-GPU box)."""
+        even when world == 1 (exercises the RCCL path on a one-GPU box).  gather_every: F > 1 gathers only every F-th
+        frame (frames F-1, 2F-1, …); the frames in between render into the same buffer set, and the sets swap at each
+        gather, so the collective of a batch runs behind the whole next batch."""
         self.tr, self.W, self.H, self.world, self.rank = tracer, W, H, world, rank
         mode = {True: "fp32", False: "none"}.get(gather, gather)
         if mode not in ("fp32", "rgba8", "none"):
             raise ValueError(f"gather={gather!r}")
         self.mode = mode if (world > 1 or force_collective) else "none"
         self.gather = self.mode != "none"
-        self.group_rows = group_rows or default_group_rows(H, world, DEFAULT_CYCLES_GATHER if self.gather else DEFAULT_CYCLES)
+        # per-frame gathers: the step is bound by the collective — one large one per frame; gathers once per batch (or none):
+        # the step is bound by the render — interleaved groups balance it, and the batch's frame is gathered group by group
+        per_frame = self.gather and max(1, int(gather_every)) == 1
+        self.group_rows = group_rows or default_group_rows(H, world, DEFAULT_CYCLES_GATHER if per_frame else DEFAULT_CYCLES)
         if world > 1 and H % (self.group_rows * world) != 0:
             raise ValueError(f"H={H} must be a multiple of group_rows*world={self.group_rows * world}")
         self.cycles = H // (self.group_rows * world) if world > 1 else 1
@@ -96,8 +107,10 @@ class TiledFrame:
         # a consumer may still read frame k)
         self.fulls = [torch.empty(H, W, 4, **gdt) for _ in range(nbuf)] if self.gather else self.locals
         self._pending = [[] for _ in range(nbuf)]   # in-flight all-gathers of each buffer set
-        self._k = 0
-        self._last = 0
+        self.gather_every = max(1, int(gather_every))
+        self._k = 0      # frames rendered
+        self._cur = 0    # buffer set the next frame renders into
+        self._last = 0   # buffer set of the most recent gathered (or, without a gather, rendered) frame
 
     @property
     def local(self):
@@ -112,7 +125,9 @@ class TiledFrame:
         if self.world == 1 and not self.gather:
             return "single GPU, full frame"
         what = {"fp32": "all_gather_into_tensor(rgba32f)", "rgba8": "post pass + all_gather_into_tensor(rgba8)"}.get(self.mode)
-        tail = (f"{self.cycles} x {what} per frame, each landing in place in the row-major frame, pipelined behind the next frame"
+        when = "per frame" if self.gather_every == 1 else f"every {self.gather_every} frames (the frame that leaves the loop)"
+        behind = "the next frame" if self.gather_every == 1 else "the next batch"
+        tail = (f"{self.cycles} x {what} {when}, each landing in place in the row-major frame, pipelined behind {behind}"
                 if self.gather else "no gather")
         return f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; {tail}"
 
@@ -129,10 +144,11 @@ class TiledFrame:
         and retire the frame that used this buffer set two steps ago.
         `events` = (start, end) torch.cuda.Events recorded around the render launches only."""
         hp = {k: v.data_ptr() for k, v in self.hits.items()}
-        b = self._k % len(self.locals)
+        b = self._cur
         self._k += 1
+        do_gather = self.gather and self._k % self.gather_every == 0
         if self.gather:
-            self._retire(b)
+            self._retire(b)   # the gather that last read this set (two gathers ago) is complete before its rows are overwritten
         if events:
             events[0].record(stream)
         if self.world == 1:
@@ -143,21 +159,27 @@ class TiledFrame:
                                      camera=camera, hit_ptrs=hp, stream=stream.cuda_stream)
         if events:
             events[1].record(stream)
-        if self.mode == "rgba8":
+        if self.mode == "rgba8" and do_gather:
             self.tr.post_dev(self.locals[b].data_ptr(), self.local_pixels, 0, self.sends[b].data_ptr(),
                              stream=stream.cuda_stream)
-        if self.gather:
+        if do_gather:
             G, span = self.group_rows if self.world > 1 else self.H, (self.group_rows * self.world if self.world > 1 else self.H)
             for c in range(self.cycles):
                 self._pending[b].append(dist.all_gather_into_tensor(
                     self.fulls[b][c * span:(c + 1) * span], self.sends[b][c * G:(c + 1) * G], async_op=True))
-        else:
+            self._cur = (b + 1) % len(self.locals)
+        elif not self.gather:
             self._last = b
         return self.fulls[b]
+
+    def restart(self):
+        """Drain the pipeline and start counting frames anew: the next gather is that of frame `gather_every` from here."""
+        self.finish()
+        self._k = 0
 
     def finish(self):
         """Drain the pipeline: every frame rendered so far is gathered; returns the last one."""
         if self.gather:
             for i in range(len(self.locals)):
-                self._retire((self._k + i) % len(self.locals))
+                self._retire((self._cur + i) % len(self.locals))   # oldest gather first: the newest one sets `full`
         return self.full
