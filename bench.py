@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--hits", default="tpn", choices=["tpn", "none"], help="first-hit record streams to write")
     ap.add_argument("--gather", default="fp32", choices=["fp32", "rgba8", "none"],
                     help="N>1: what is all-gathered (default: the rgba32f framebuffer)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="frames in flight per rank, each on its own HIP stream with its own context and output set "
+                         "(default: 1 for N = 1, 4 for N > 1 — a 1/N part of the frame does not fill the chip on one stream)")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="one GPU: run the N>1 code path (RCCL group of one rank, forced collectives) — a rehearsal, not a measurement")
     ap.add_argument("--gather-every", default="step",
@@ -447,13 +450,16 @@ def worker(a, world, rank, local):
     g = camera.baseline_camera(W, H) if a.center == "0,0,0" else camera.globals_for(
         (0.0, 1.5, -4.0), tuple(float(v) for v in a.center.split(",")), W, H)
     pc = camera.baseline_push(a.depth)
-    tr = Tracer(local)
+    n_streams = a.streams if a.streams > 0 else (4 if world > 1 else 1)
+    trs = [Tracer(local) for _ in range(n_streams)]
+    tr = trs[0]
     if a.variant:
-        tr.set_render_variant(a.variant)
+        for t_ in trs:
+            t_.set_render_variant(a.variant)
     variant = tr.render_variant()
 
     gather_every = F if a.gather_every == "step" else max(1, int(a.gather_every))
-    frame = trtd.TiledFrame(tr, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else (),
+    frame = trtd.TiledFrame(trs, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else (),
                             gather=a.gather, group_rows=a.group_rows or None, gather_every=gather_every,
                             force_collective=a.rehearse_collective)
     stream = torch.cuda.current_stream()
@@ -498,6 +504,7 @@ def worker(a, world, rank, local):
         for f in range(F):
             one_frame(evs[k * F + f] if per_frame else None)
         if not per_frame:
+            frame.join(stream)   # several render streams: `stream` continues behind all of them (a no-op with one)
             evs[k][1].record(stream)
     frame.finish()   # N > 1: the last frames' all-gathers are part of the K steps
     torch.cuda.synchronize()
@@ -580,6 +587,7 @@ def worker(a, world, rank, local):
             "gather_ms": gather_ms,
             "gather_every_frames": (gather_every if frame.gather else None),
             "rehearse_collective": bool(a.rehearse_collective),
+            "frames_in_flight": n_streams,
             # the rank-local renders alone (max over ranks of the HIP-event render time per frame): the part of the path that
             # shards; `value` above includes replicating the framebuffer on every GPU, as north_star prescribes
             "render_only_primary_tests_per_s": cnt["primary_tests"] / (kern_ms_max * 1e-3) if multi else None,
@@ -610,7 +618,8 @@ def worker(a, world, rank, local):
     if multi:
         dist.barrier()
         dist.destroy_process_group()
-    tr.close()
+    for t_ in trs:
+        t_.close()
 
 
 def main():

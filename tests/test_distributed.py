@@ -111,11 +111,18 @@ def _worker(rank, world, port, W, H, G, out):
         for depth in (1, 2, 1, 3, 1):
             frameb.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
         fullb = frameb.finish().clone()
+        # three frames in flight (three contexts, three output sets; on the CPU the "streams" are synchronous), a gather
+        # every 4th frame: frames 3 and 7 are gathered — from output sets 0 and 1 — and frame 7 (maxDepth 3) is handed out
+        framek = trtd.TiledFrame([tr, _OracleTracer(), _OracleTracer()], W, H, world, rank, torch.device("cpu"), gather_every=4)
+        assert "3 frames in flight" in framek.describe() and len(framek.locals) == 3
+        for depth in (1, 2, 1, 2, 1, 2, 1, 3, 1):
+            framek.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
+        fullk = framek.finish().clone()
         if rank == 0:
             want, _, _, _ = tr.oracle.render(sc, g, camera.baseline_push(3), W, H, want_hits=False)
             ok = bool(np.array_equal(full.numpy(), want))
             ok = ok and full8.dtype == torch.uint8 and bool(np.array_equal(full8.numpy(), tr.oracle.post(want)[1]))
-            ok = ok and bool(np.array_equal(fullb.numpy(), want))
+            ok = ok and bool(np.array_equal(fullb.numpy(), want)) and bool(np.array_equal(fullk.numpy(), want))
             out.put(ok)
         dist.barrier()
     finally:

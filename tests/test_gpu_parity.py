@@ -515,6 +515,24 @@ def test_rccl_collective_path_world_1(tr):
         full = frame.finish()
         torch.cuda.synchronize()
         assert torch.equal(full.view(torch.int32), want.view(torch.int32))
+        # three frames in flight on three HIP streams (three contexts, three output sets), one gather every 4 frames:
+        # frames 3 and 7 are gathered (the second one is the maxDepth-3 frame), the caller's stream sees them after finish()
+        from toroidal_ray_tracing_amd.tracer import Tracer
+        extra = [Tracer(0), Tracer(0)]
+        try:
+            frame = trtd.TiledFrame([tr] + extra, W, H, 1, 0, dev, gather="fp32", force_collective=True, gather_every=4,
+                                    want_hits=("t", "id"))
+            for depth in (1, 2, 5, 2, 1, 2, 5, 3, 1, 2):
+                frame.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, stream)
+            full = frame.finish()
+            last3 = [frame.locals[k].clone() for k in range(3)]   # frames 9, 7, 8 (maxDepth 2, 3, 1) on sets 0, 1, 2
+            torch.cuda.synchronize()
+            assert torch.equal(full.view(torch.int32), want.view(torch.int32))
+            assert torch.equal(last3[1].view(torch.int32), want.view(torch.int32))
+            assert not torch.equal(last3[0].view(torch.int32), want.view(torch.int32))
+        finally:
+            for t in extra:
+                t.close()
     finally:
         dist.destroy_process_group()
 

@@ -61,56 +61,84 @@ def deinterleave(gathered, H, W, group_rows, n_parts, channels=4):
     return v.permute(1, 0, 2, 3, 4).reshape(H, W, channels)
 
 
-class TiledFrame:
-    """Framebuffer + first-hit streams of one rank, and the per-frame render/gather step.
+class _NullStream:
+    """Stands in for a HIP stream on the CPU (gloo rehearsals and tests): everything is synchronous."""
+    cuda_stream = 0
 
-    With world > 1 the step is software-pipelined over two buffer sets: the all-gathers of
-    frame k (RCCL, asynchronous on the process group's stream) run while frame k+1 renders, so
-    the frame rate is max(render, gather) instead of their sum; ``finish()`` drains the pipe and
-    returns the last complete row-major frame.
+    def wait_event(self, ev):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+
+class TiledFrame:
+    """Framebuffer + first-hit streams of one rank, and the per-frame render / per-batch gather step.
+
+    Frames are independent, so K of them can be in flight at once: `streams=K` gives every frame one of K HIP streams
+    in turn, each with its own context (tile lists, counters) and its own output set.  A 1/8 part of the baseline frame
+    is latency-bound on one stream — one frame's traced tiles do not fill the chip, and the next frame's kernels wait for
+    the slowest of them: 41 µs per frame; on 2 / 3 / 4 streams 21.5 / 17.7 / 16.4 µs (tools/bench_tiled_streams.py).
+
+    A gathered frame is first copied (fp32) or tonemapped (rgba8) into one of two staging buffers — 1/N of the frame,
+    once per gather — and the all-gathers read the staging copy on the process group's stream: no render stream ever
+    waits for a link-bound collective, and the collective of a batch runs behind the whole next batch.  ``finish()``
+    drains everything and returns the last complete row-major frame.
     """
 
     def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=None,
                  gather=True, force_collective=False, gather_every=1):
-        """gather: True / "fp32" — all-gather the rgba32f framebuffer (default, what north_star
+        """tracer: one Tracer, or a list of K of them (K render streams, one context each).
+        gather: True / "fp32" — all-gather the rgba32f framebuffer (default, what north_star
         prescribes); "rgba8" — tonemap each rank's rows (trt_post_dev, post.frag) and all-gather
         the 8-bit image a swapchain would present: 4x fewer bytes over xGMI, the rgba32f image
         stays sharded; False / "none" — no collective.  force_collective: issue the collective
         even when world == 1 (exercises the RCCL path on a one-GPU box).  gather_every: F > 1 gathers only every F-th
-        frame (frames F-1, 2F-1, …); the frames in between render into the same buffer set, and the sets swap at each
-        gather, so the collective of a batch runs behind the whole next batch."""
-        self.tr, self.W, self.H, self.world, self.rank = tracer, W, H, world, rank
+        frame (frames F-1, 2F-1, …)."""
+        self.trs = list(tracer) if isinstance(tracer, (list, tuple)) else [tracer]
+        self.tr = self.trs[0]
+        self.W, self.H, self.world, self.rank = W, H, world, rank
         mode = {True: "fp32", False: "none"}.get(gather, gather)
         if mode not in ("fp32", "rgba8", "none"):
             raise ValueError(f"gather={gather!r}")
         self.mode = mode if (world > 1 or force_collective) else "none"
         self.gather = self.mode != "none"
+        self.gather_every = max(1, int(gather_every))
         # per-frame gathers: the step is bound by the collective — one large one per frame; gathers once per batch (or none):
         # the step is bound by the render — interleaved groups balance it, and the batch's frame is gathered group by group
-        per_frame = self.gather and max(1, int(gather_every)) == 1
+        per_frame = self.gather and self.gather_every == 1
         self.group_rows = group_rows or default_group_rows(H, world, DEFAULT_CYCLES_GATHER if per_frame else DEFAULT_CYCLES)
         if world > 1 and H % (self.group_rows * world) != 0:
             raise ValueError(f"H={H} must be a multiple of group_rows*world={self.group_rows * world}")
         self.cycles = H // (self.group_rows * world) if world > 1 else 1
         self.tiling = abi.trt_tiling(self.group_rows, world, rank, 1 if world > 1 else 0)
-        self.local_rows = tracer.tiling_rows(self.tiling, H) if world > 1 else H
+        self.local_rows = self.tr.tiling_rows(self.tiling, H) if world > 1 else H
         self.local_pixels = self.local_rows * W
+        self.device = torch.device(device)
+        K = len(self.trs)
         f32 = dict(dtype=torch.float32, device=device)
-        nbuf = 2 if self.gather else 1
-        self.locals = [torch.empty(self.local_rows, W, 4, **f32) for _ in range(nbuf)]
-        self.hits = {k: torch.empty(self.local_pixels, **f32) for k in want_hits if k != "id"}
-        if "id" in want_hits:
-            self.hits["id"] = torch.empty(self.local_pixels, dtype=torch.int32, device=device)
+        # one output set per render stream
+        self.locals = [torch.empty(self.local_rows, W, 4, **f32) for _ in range(K)]
+        self.hit_sets = []
+        for _ in range(K):
+            h = {k: torch.empty(self.local_pixels, **f32) for k in want_hits if k != "id"}
+            if "id" in want_hits:
+                h["id"] = torch.empty(self.local_pixels, dtype=torch.int32, device=device)
+            self.hit_sets.append(h)
+        self.hits = self.hit_sets[0]
+        # K > 1: the render streams are this object's own; K == 1: the caller's stream is the render stream
+        cuda = self.device.type == "cuda"
+        self._own = [torch.cuda.Stream(device=self.device) if cuda else _NullStream() for _ in range(K)] if K > 1 else None
+        self._forked = False
+        self._caller = None
+        # two staging buffers and two gathered frames: gather j+1 is issued while a consumer may still read frame j
         gdt = dict(dtype=torch.uint8 if self.mode == "rgba8" else torch.float32, device=device)
-        self.sends = [torch.empty(self.local_rows, W, 4, **gdt) for _ in range(nbuf)] if self.mode == "rgba8" else self.locals
-        # the gathered frame, row-major [H, W, 4] — one per buffer set (frame k+1 is gathered while
-        # a consumer may still read frame k)
-        self.fulls = [torch.empty(H, W, 4, **gdt) for _ in range(nbuf)] if self.gather else self.locals
-        self._pending = [[] for _ in range(nbuf)]   # in-flight all-gathers of each buffer set
-        self.gather_every = max(1, int(gather_every))
-        self._k = 0      # frames rendered
-        self._cur = 0    # buffer set the next frame renders into
-        self._last = 0   # buffer set of the most recent gathered (or, without a gather, rendered) frame
+        self.sends = [torch.empty(self.local_rows, W, 4, **gdt) for _ in range(2)] if self.gather else []
+        self.fulls = [torch.empty(H, W, 4, **gdt) for _ in range(2)] if self.gather else self.locals
+        self._pending = [[], []]   # in-flight all-gathers reading staging buffer j
+        self._stage = 0            # staging buffer of the next gather
+        self._k = 0                # frames rendered
+        self._last = 0             # gathered frame (or, without a gather, output set) handed out by `full`
 
     @property
     def local(self):
@@ -118,7 +146,7 @@ class TiledFrame:
 
     @property
     def full(self):
-        """The most recent complete frame (after ``finish()``: the last one rendered)."""
+        """The most recent complete frame: the last GATHERED one (without a gather: the last one rendered)."""
         return self.fulls[self._last]
 
     def describe(self):
@@ -129,48 +157,77 @@ class TiledFrame:
         behind = "the next frame" if self.gather_every == 1 else "the next batch"
         tail = (f"{self.cycles} x {what} {when}, each landing in place in the row-major frame, pipelined behind {behind}"
                 if self.gather else "no gather")
-        return f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; {tail}"
+        k = f"; {len(self.trs)} frames in flight on {len(self.trs)} streams" if len(self.trs) > 1 else ""
+        return f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; {tail}{k}"
 
-    def _retire(self, b):
-        """Wait for the gathers of buffer set b: its row-major frame is then complete."""
-        if self._pending[b]:
-            for w in self._pending[b]:
-                w.wait()   # orders the current stream behind the collective
-            self._pending[b] = []
-            self._last = b
+    def _on(self, stream):
+        import contextlib
+        return torch.cuda.stream(stream) if self.device.type == "cuda" else contextlib.nullcontext()
+
+    def _retire(self, j):
+        """Order the current stream behind the gathers that read staging buffer j: gathered frame j is then complete."""
+        if self._pending[j]:
+            for w in self._pending[j]:
+                w.wait()
+            self._pending[j] = []
+            self._last = j
 
     def render(self, scene, g, pc, camera, stream, events=None):
-        """One frame: render this rank's rows; when gathering, start the all-gathers of this frame
-        and retire the frame that used this buffer set two steps ago.
+        """One frame: render this rank's rows on the frame's stream (the caller's `stream`, or with K tracers the next of
+        the K own streams, which branch off `stream` at the first frame after construction / join()); on a gather frame
+        copy or tonemap the rows into a staging buffer and start the all-gathers behind that.
         `events` = (start, end) torch.cuda.Events recorded around the render launches only."""
-        hp = {k: v.data_ptr() for k, v in self.hits.items()}
-        b = self._cur
+        K = len(self.trs)
+        k = self._k % K
         self._k += 1
-        do_gather = self.gather and self._k % self.gather_every == 0
-        if self.gather:
-            self._retire(b)   # the gather that last read this set (two gathers ago) is complete before its rows are overwritten
-        if events:
-            events[0].record(stream)
-        if self.world == 1:
-            self.tr.render_dev(scene, g, pc, self.W, self.H, self.locals[b].data_ptr(), camera=camera,
-                               hit_ptrs=hp, stream=stream.cuda_stream)
+        self._caller = stream
+        if self._own is not None:
+            if not self._forked:
+                if self.device.type == "cuda":
+                    for s in self._own:
+                        s.wait_stream(stream)
+                self._forked = True
+            s = self._own[k]
         else:
-            self.tr.render_tiled_dev(scene, g, pc, self.W, self.H, self.tiling, self.locals[b].data_ptr(),
-                                     camera=camera, hit_ptrs=hp, stream=stream.cuda_stream)
+            s = stream
+        tr, hp = self.trs[k], {n: v.data_ptr() for n, v in self.hit_sets[k].items()}
+        do_gather = self.gather and self._k % self.gather_every == 0
         if events:
-            events[1].record(stream)
-        if self.mode == "rgba8" and do_gather:
-            self.tr.post_dev(self.locals[b].data_ptr(), self.local_pixels, 0, self.sends[b].data_ptr(),
-                             stream=stream.cuda_stream)
+            events[0].record(s)
+        if self.world == 1:
+            tr.render_dev(scene, g, pc, self.W, self.H, self.locals[k].data_ptr(), camera=camera, hit_ptrs=hp, stream=s.cuda_stream)
+        else:
+            tr.render_tiled_dev(scene, g, pc, self.W, self.H, self.tiling, self.locals[k].data_ptr(), camera=camera,
+                                hit_ptrs=hp, stream=s.cuda_stream)
+        if events:
+            events[1].record(s)
         if do_gather:
-            G, span = self.group_rows if self.world > 1 else self.H, (self.group_rows * self.world if self.world > 1 else self.H)
-            for c in range(self.cycles):
-                self._pending[b].append(dist.all_gather_into_tensor(
-                    self.fulls[b][c * span:(c + 1) * span], self.sends[b][c * G:(c + 1) * G], async_op=True))
-            self._cur = (b + 1) % len(self.locals)
-        elif not self.gather:
-            self._last = b
-        return self.fulls[b]
+            j = self._stage
+            self._stage ^= 1
+            with self._on(s):
+                self._retire(j)   # the gather that read this staging buffer two gathers ago is complete before it is overwritten
+                if self.mode == "rgba8":
+                    tr.post_dev(self.locals[k].data_ptr(), self.local_pixels, 0, self.sends[j].data_ptr(), stream=s.cuda_stream)
+                else:
+                    self.sends[j].copy_(self.locals[k], non_blocking=True)
+                G, span = self.group_rows if self.world > 1 else self.H, (self.group_rows * self.world if self.world > 1 else self.H)
+                for c in range(self.cycles):
+                    self._pending[j].append(dist.all_gather_into_tensor(
+                        self.fulls[j][c * span:(c + 1) * span], self.sends[j][c * G:(c + 1) * G], async_op=True))
+            return self.fulls[j]
+        if not self.gather:
+            self._last = k
+        return self.fulls[self._last]
+
+    def join(self, stream=None):
+        """K own streams: order `stream` (default: the stream of the last render call) behind every frame issued so far;
+        the next render() branches off again."""
+        stream = stream or self._caller
+        if self._own is not None and self._forked and stream is not None:
+            if self.device.type == "cuda":
+                for s in self._own:
+                    stream.wait_stream(s)
+            self._forked = False
 
     def restart(self):
         """Drain the pipeline and start counting frames anew: the next gather is that of frame `gather_every` from here."""
@@ -178,8 +235,11 @@ class TiledFrame:
         self._k = 0
 
     def finish(self):
-        """Drain the pipeline: every frame rendered so far is gathered; returns the last one."""
+        """Drain the pipeline: every frame issued so far is rendered, every gather started is complete on the caller's
+        stream; returns the last gathered frame."""
+        self.join()
         if self.gather:
-            for i in range(len(self.locals)):
-                self._retire((self._cur + i) % len(self.locals))   # oldest gather first: the newest one sets `full`
+            with self._on(self._caller) if self._caller is not None else self._on(None):
+                for i in range(2):
+                    self._retire(self._stage ^ i)   # oldest gather first: the newest one sets `full`
         return self.full
