@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does overlapping consecutive frames on K streams (one trt_ctx + one output set per stream) lift the latency floor of a
-1/N part?  usage: bench_tiled_streams.py [--parts 8] [--part 0] [--streams 1 2 3 4]"""
+1/N part?  usage: bench_tiled_streams.py [--parts 8] [--part 0] [--streams 1 2 3 4] [--scene nested] [--f64]"""
 import argparse, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,15 +13,21 @@ ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--parts", type=int, default=8)
 ap.add_argument("--part", type=int, default=0)
 ap.add_argument("--streams", type=int, nargs="+", default=[1, 2, 3, 4])
+ap.add_argument("--scene", default="single", choices=["single", "nested"], help="nested: the eight nested tori of config 4")
+ap.add_argument("--f64", action="store_true", help="FP64 solve (config 4)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 W = H = a.size
-sc, g, pc = camera.single_torus_scene(), camera.baseline_camera(W, H), camera.baseline_push(5)
+sc = camera.single_torus_scene() if a.scene == "single" else camera.nested_tori_scene()
+g, pc = camera.baseline_camera(W, H), camera.baseline_push(5)
 n = a.parts
 G = trtd.default_group_rows(H, n, trtd.DEFAULT_CYCLES) if n > 1 else H
 t = abi.trt_tiling(G, n, a.part, 1 if n > 1 else 0)
 for K in a.streams:
     trs = [Tracer(0) for _ in range(K)]
+    if a.f64:
+        for tr_ in trs:
+            tr_.set_solver(abi.TRT_SOLVE_F64)
     streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
     rows = trs[0].tiling_rows(t, H) if n > 1 else H
     bufs = [(torch.empty(rows, W, 4, device=dev), {k: torch.empty(rows * W, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}) for _ in range(K)]
@@ -45,6 +51,6 @@ for K in a.streams:
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / 256)
     ms = statistics.median(out) * 1e3
-    print(f"{n} parts, part {a.part}, {K} stream(s): {ms * 1e3:.1f} us per frame (wall, 256 frames)", flush=True)
+    print(f"{a.scene}{' f64' if a.f64 else ''}: {n} parts, part {a.part}, {K} stream(s): {ms * 1e3:.1f} us per frame (wall, 256 frames)", flush=True)
     for tr in trs:
         tr.close()
