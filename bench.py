@@ -302,44 +302,6 @@ def secondary(tr, dev, stream):
 
     render_case("C4 8 nested tori, 4096^2, maxDepth 5, FP64 solve", camera.nested_tori_scene(), camera.baseline_camera(W, W),
                 camera.baseline_push(5), solver=abi.TRT_SOLVE_F64)
-    # config 4 as a frame LOOP with two frames in flight: a second context on a second stream with its own output set.  The
-    # frame's tail — a few very heavy tiles running out on an otherwise idle chip — is filled by the next frame.
-    from toroidal_ray_tracing_amd.tracer import Tracer
-    tr2 = Tracer(dev.index or 0)
-    try:
-        _abi = abi
-        sc8, g8, pc8 = camera.nested_tori_scene(), camera.baseline_camera(W, W), camera.baseline_push(5)
-        rgba2 = torch.empty(W, W, 4, device=dev)
-        hits2 = {k: torch.empty(n, device=dev) for k in hits}
-        pair = [(tr, rgba.data_ptr(), hp, torch.cuda.Stream(device=dev)), (tr2, rgba2.data_ptr(), {k: v.data_ptr() for k, v in hits2.items()}, torch.cuda.Stream(device=dev))]
-        tr.set_solver(_abi.TRT_SOLVE_F64)
-        tr2.set_solver(_abi.TRT_SOLVE_F64)
-        cur = stream
-
-        def two_in_flight(reps=32):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-            for _, _, _, st_ in pair:
-                st_.wait_stream(cur)
-            for i in range(reps):
-                t_, r_, h_, st_ = pair[i & 1]
-                t_.render_dev(sc8, g8, pc8, W, W, r_, hit_ptrs=h_, stream=st_.cuda_stream)
-            for _, _, _, st_ in pair:
-                cur.wait_stream(st_)
-            e1.record(cur)
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
-
-        two_in_flight(8)
-        ms = statistics.median(two_in_flight() for _ in range(5))
-        res.append({"name": "C4 8 nested tori, FP64 solve, TWO frames in flight (two contexts on two streams)", "ms": ms, "units": n,
-                    "GB_per_s": BYTES_PER_PIXEL * n / ms / 1e6, "frac_hbm": BYTES_PER_PIXEL * n / ms / 1e6 / HBM_PEAK_GBPS, "dtype": "f64",
-                    "bound": "valu", "kernel": "classify + render_listed_kernel<double>, two launches overlapping",
-                    "primary_tests_per_s": n * sc8.n_tori / ms * 1e3})
-        del rgba2, hits2
-    finally:
-        tr.set_solver(abi.TRT_SOLVE_F32)
-        tr2.close()
     render_case("C3 with the persistent-threads variant", camera.single_torus_scene(), camera.baseline_camera(W, W),
                 camera.baseline_push(5), variant="persistent")
     # the headline frame into FOUR alternating output sets (3 GB): the headline — like the reference's frame loop — writes
