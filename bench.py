@@ -552,13 +552,18 @@ def worker(a, world, rank, local):
 
     # HBM bytes per launch from the PMC passes of tools/make_profiles.sh (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE,
     # separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The file records the
-    # kernel build it was measured on; a stale file yields null, not an old number.
+    # kernel sources it was measured on (sha256 written by make_profiles.sh ON the GPU box): other sources, or another
+    # size / depth, yield null, not an old number.
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("size") == a.size and tj.get("depth") == a.depth:
+            import hashlib
+            h = hashlib.sha256()
+            for f in ("trt_kernels.hip", "trt_device.hpp", "trt_kernels.hpp", "trt_api.hip"):
+                h.update(open(os.path.join(ROOT, "toroidal_ray_tracing_amd", "csrc", f), "rb").read())
+            if tj.get("size") == a.size and tj.get("depth") == a.depth and tj.get("kernel_sources_sha256") == h.hexdigest():
                 traffic = tj.get(variant, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None

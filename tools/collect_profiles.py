@@ -54,6 +54,9 @@ for k, d in summary.items():
         # WRITE_SIZE is exact for 16-B-per-lane streaming stores (this kernel's dominant stores).
         fetch += 2.0 * 1024.0 * d.get("FETCH_SIZE", {}).get("per_launch_median", 0.0)
         write += 1024.0 * d.get("WRITE_SIZE", {}).get("per_launch_median", 0.0)
+shafile = os.path.join(src, "kernel_sources.sha256")
+if os.path.exists(shafile):
+    traffic["kernel_sources_sha256"] = open(shafile).read().strip()
 traffic["size"], traffic["depth"] = 4096, 5   # the workload of the passes (bench.py defaults); bench.py ignores the file for any other
 traffic[variant] = {"hbm_bytes_per_launch": fetch + write, "write_bytes": write, "fetch_bytes_corrected": fetch,
                     "note": "classify + render kernels of one frame; FETCH_SIZE doubled per the gfx950 correction"}

@@ -7,6 +7,9 @@ set -u
 ROUND=${1:-r01}; V=${2:-listed}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles_$ROUND
 mkdir -p $OUT
+# the kernel sources these passes measure: bench.py reports `roofline.traffic` only while they are unchanged
+cat $R/toroidal_ray_tracing_amd/csrc/trt_kernels.hip $R/toroidal_ray_tracing_amd/csrc/trt_device.hpp $R/toroidal_ray_tracing_amd/csrc/trt_kernels.hpp \
+    $R/toroidal_ray_tracing_amd/csrc/trt_api.hip | sha256sum | cut -d" " -f1 > $OUT/kernel_sources.sha256
 cd /tmp && export TMPDIR=/tmp
 # 1. per-kernel time of the SAME command the driver runs (kernel trace + stats only)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --variant $V --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || tail -5 $OUT/trace.err
