@@ -12,11 +12,12 @@ of the tiling is N consecutive groups = G·N consecutive image rows, group p of 
 rank p — so the all-gather of the ranks' c-th groups, ``all_gather_into_tensor(frame[c·G·N :
 (c+1)·G·N], local[c·G : (c+1)·G])``, lands every row AT ITS PLACE in the row-major frame: the
 gathered frame needs no de-interleaving copy (round 1 paid 2 × 268 MB of HBM traffic per frame
-for one).  How many cycles: when the frame is gathered the step is bound by the collective, not by
+for one).  How many cycles: when EVERY frame is gathered the step is bound by the collective, not by
 the render, so ONE cycle — plain row bands, one large collective per frame, no launch
 overhead of eight small ones (xGMI is point-to-point, 7 links per GPU; RCCL spreads a large
-collective over all of them); without a gather (`gather="none"`) eight cycles, an interleaving
-fine enough to balance the load (the torus sits in the middle rows).
+collective over all of them); with a gather per batch, or none, eight cycles: an interleaving
+fine enough to balance the load (the torus sits in the middle rows), and the batch's frame is
+gathered group by group.
 
 How often: `gather_every` = F gathers only every F-th frame — the frame that leaves the render loop.  The reference's
 loop renders 60 frames per camera radius and reads the image back once, after the 60th (BEF/main.cpp:339-343 `counter ==
@@ -29,8 +30,8 @@ import torch.distributed as dist
 
 from . import abi
 
-DEFAULT_CYCLES = 8          # groups per rank without a gather (load balance)
-DEFAULT_CYCLES_GATHER = 1   # … and with one: a single collective per frame
+DEFAULT_CYCLES = 8          # groups per rank when the render binds the step: a gather per batch, or none (load balance)
+DEFAULT_CYCLES_GATHER = 1   # … and with a gather after EVERY frame: a single collective per frame
 
 
 def default_group_rows(H, world, cycles=DEFAULT_CYCLES):
