@@ -757,6 +757,54 @@ def test_unaligned_hit_streams(tr, variant):
         assert big[k][:off[k]].abs().sum().item() == 0 and big[k][off[k] + W * H:].abs().sum().item() == 0   # nothing written outside
 
 
+def test_cost_feedback_orders_tiles_and_changes_nothing():
+    """Cost feedback: from the second frame on a multi-torus scene's heavy tiles are traced first — the
+    order of the LIVE list is the ONLY thing that may change.  Four frames of the eight nested tori through one context:
+    image, first-hit streams and every query / work counter bit-identical from frame to frame; then a different size and a
+    single-torus frame in between (stale costs of another geometry must be harmless), and the first frame again."""
+    import torch
+    from toroidal_ray_tracing_amd.tracer import Tracer
+    dev = torch.device("cuda:0")
+    t = Tracer(0)
+    s = torch.cuda.current_stream().cuda_stream
+    try:
+        sc8, sc1 = camera.nested_tori_scene(), camera.single_torus_scene()
+
+        def frame(sc, W, H, depth=5, stats=False, rendered=False):
+            g, pc = camera.baseline_camera(W, H), camera.baseline_push(depth)
+            rgba = torch.full((H, W, 4), -3.0, device=dev)
+            hits = {k: torch.full((H * W,), -3.0, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}
+            rend = torch.full((W * H, 16), -3.0, device=dev) if rendered else None
+            t.enable_stats(stats)   # (the counted instantiations take no part in the feedback: they neither time nor reorder)
+            t.render_dev(sc, g, pc, W, H, rgba.data_ptr(), hit_ptrs={k: v.data_ptr() for k, v in hits.items()},
+                         rendered_ptr=rend.data_ptr() if rendered else 0, stream=s)
+            torch.cuda.synchronize()
+            return [rgba] + [hits[k] for k in sorted(hits)] + ([rend] if rendered else []), (t.stats() if stats else None)
+
+        same = lambda a, b: all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(a, b))
+        ref, st0 = frame(sc8, 1024, 768, stats=True)       # counted: no history is written
+        for k in range(4):                                   # first of these without history, the others heavy-first
+            got, _ = frame(sc8, 1024, 768)
+            assert same(ref, got), f"frame {k + 2}"
+        got, st = frame(sc8, 1024, 768, stats=True)        # a counted frame consumes nothing and counts the same
+        assert same(ref, got) and st == st0
+        refr, _ = frame(sc8, 1024, 768, rendered=True)     # the RenderedData instantiation takes part too
+        for k in range(2):
+            got, _ = frame(sc8, 1024, 768, rendered=True)
+            assert same(refr, got)
+        frame(sc8, 520, 264)       # another geometry: the cost words now belong to other tiles
+        frame(sc1, 1024, 768)      # a single-torus frame does not use them at all
+        got, _ = frame(sc8, 1024, 768)
+        assert same(ref, got)
+        t.set_solver(abi.TRT_SOLVE_F64)
+        ref64, _ = frame(sc8, 1024, 768)
+        for k in range(2):
+            got, _ = frame(sc8, 1024, 768)
+            assert same(ref64, got)
+    finally:
+        t.close()
+
+
 def test_frame_sequences_keep_no_state(oracle):
     """One ctx, 40 frames in a row that change size, camera model, scene, kernel variant, solver and
     depth at random: every frame must equal the oracle's — nothing (tile lists, their

@@ -58,6 +58,7 @@ struct trt_ctx {
   // staging for the host-pointer entry points (grow-only, freed in trt_destroy)
   DevBuf d_in[6], d_out[8], d_rgba, d_rendered;
   DevBuf d_tiles;  // LIVE + CLEAR tile lists of the persistent kernel
+  DevBuf d_cost;   // cost feedback: one word per macro tile (zero = no history)
   DevBuf d_keys;   // depth|index keys of trt_splat_dev (one-pass form)
   DevBuf d_bins;   // … binned form: per-bin count / offset / cursor words (count zero between calls)
   DevBuf d_recs;   // … binned form: point records sorted by bin
@@ -328,7 +329,7 @@ extern "C" void trt_destroy(trt_ctx* ctx)
   if(ctx->d_stats) (void)hipFree(ctx->d_stats);
   if(ctx->d_queue) (void)hipFree(ctx->d_queue);
   if(ctx->h_toro) (void)hipHostFree(ctx->h_toro);
-  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered, &ctx->d_tiles, &ctx->d_keys, &ctx->d_bins, &ctx->d_recs};
+  DevBuf* all[] = {&ctx->d_toro, &ctx->d_rgba, &ctx->d_rendered, &ctx->d_tiles, &ctx->d_cost, &ctx->d_keys, &ctx->d_bins, &ctx->d_recs};
   for(DevBuf* b : all)
     if(b->p) (void)hipFree(b->p);
   for(DevBuf& b : ctx->d_in)
@@ -576,6 +577,20 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     a.tiles_clear = a.tiles_live + n_tiles;
     a.cap_live    = (uint32_t)n_tiles;
     a.cap_clear   = (uint32_t)n_tiles;
+    // cost feedback of the listed kernel (scheduling only): one word per macro tile, zero when the buffer is new.  It pays
+    // where the cost of a tile varies much and the frame is bound by the tracing: eight nested tori −11 % (FP64) / −15 %
+    // (FP32); a single torus' frame is bound by its stores and LOSES 2–3 % to the bookkeeping — scenes of one torus go without
+    if(ctx->variant == kRenderListed && ctx->tn.heavy_x16 && (uint32_t)S.n_tori >= ctx->tn.heavy_min_tori)
+    {
+      const size_t n_macro = (size_t)(((W + 7) / 8 + 3) / 4) * ((a.n_local_rows + 7) / 8);
+      if(ctx->d_cost.cap < n_macro * sizeof(uint32_t))
+      {
+        if(int rc = grow(ctx, ctx->d_cost, n_macro * sizeof(uint32_t), st)) return rc;
+        TRT_HIP(ctx, hipMemsetAsync(ctx->d_cost.p, 0, ctx->d_cost.cap, st));   // never inside a capture: grow() refuses there
+      }
+      a.tile_cost = (uint32_t*)ctx->d_cost.p;
+      a.heavy_x16 = ctx->tn.heavy_x16;
+    }
     // tile culling needs tiles that are 8 contiguous image rows; with a RenderedData export the listed
     // kernel still writes the primary ray and the miss record of every pixel of a culled tile (raygen
     // only, no solve), the persistent kernel does not: it then traces every tile
@@ -616,10 +631,10 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
   }
   if(ctx->variant != kRenderStatic && ctx->tn.debug_tiles)
   {
-    unsigned int q[2];
+    unsigned int q[4];
     TRT_HIP(ctx, hipStreamSynchronize(st));
     TRT_HIP(ctx, hipMemcpy(q, a.counts, sizeof q, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[trt] tiles: live=%u clear=%u (cull=%u)\n", q[0], q[1], a.tile_cull);
+    fprintf(stderr, "[trt] tiles: live=%u (heavy %u, mean cost %u ticks) clear=%u (cull=%u)\n", q[0], q[2], q[3], q[1], a.tile_cull);
   }
   return TRT_OK;
 }

@@ -628,12 +628,23 @@ __device__ __forceinline__ void classify_publish(const RenderArgs& a, unsigned i
     }
     if(last)
     {
-      const unsigned int n_live = atomicExch(&a.counters[0], 0u), n_clear = atomicExch(&a.counters[1], 0u);
-      a.counts[0] = n_live < a.cap_live ? n_live : a.cap_live;
+      const unsigned int n_norm = atomicExch(&a.counters[0], 0u), n_clear = atomicExch(&a.counters[1], 0u);
+      const unsigned int n_heavy = atomicExch(&a.counters[3], 0u);
+      const unsigned int cost_sum = atomicExch(&a.counters[4], 0u), cost_cnt = atomicExch(&a.counters[5], 0u);
+      const unsigned int n_live = n_norm + n_heavy < a.cap_live ? n_norm + n_heavy : a.cap_live;   // (their sum never exceeds the tiles)
+      a.counts[0] = n_live;
       a.counts[1] = n_clear < a.cap_clear ? n_clear : a.cap_clear;
+      a.counts[2] = n_heavy < n_live ? n_heavy : n_live;
+      a.counts[3] = cost_cnt ? cost_sum / cost_cnt : 0u;   // the threshold of the NEXT frame's classification
       atomicExch(&a.counters[2], 0u);
     }
   }
+}
+
+// Logical LIVE entry L → position in tiles_live (RenderArgs::tile_cost): the heavy tiles come first.
+__device__ __forceinline__ size_t live_slot(uint32_t cap_live, uint32_t n_heavy, uint64_t L)
+{
+  return L < n_heavy ? (size_t)cap_live - 1 - (size_t)L : (size_t)(L - n_heavy);
 }
 
 // Block size of the classification kernels: the largest there is.  Every block reserves its stretch of each list with ONE
@@ -646,17 +657,88 @@ __device__ __forceinline__ void classify_publish(const RenderArgs& a, unsigned i
 constexpr int kClassifyThreads = TRT_CLASSIFY_THREADS;
 constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8×8 tiles = 32×8 pixels
 
+// What the two classification kernels share.  Per lane: the LIVE tiles it contributes, as NORMAL ones in the low and as
+// HEAVY ones in the high half of ONE word (a wave holds at most 256 of either, a block 4,096: the halves never carry
+// into each other), its CLEAR macro tile, and the macro tile's previous cost.  Three wave scans (as many shuffles as two
+// lists cost before, plus one), a ballot for the number of macro tiles with a cost.  Rows of wave_cnt: 0 packed LIVE
+// totals per wave, 1 CLEAR (turned into its prefix in place), 2 cost sums, 3 cost counts, 4 exclusive prefix of row 0.
+// Threads 0, 1, 2 reserve the block's stretch of the NORMAL / CLEAR / HEAVY list (a.counters[0], [1], [3]), threads 3 and
+// 4 add the block's cost sum and count (a.counters[4], [5]) — five RETURNING atomics whose results are in LDS before
+// the barrier, hence performed before the block's ticket.
+constexpr int kClassifyRows = 5;
+
+__device__ __forceinline__ uint32_t classify_take_cost(const RenderArgs& a, bool owner, uint32_t macro)
+{
+  if(!a.tile_cost || !owner)
+    return 0u;
+  const uint32_t c = a.tile_cost[macro];
+  if(c) a.tile_cost[macro] = 0u;
+  return c;
+}
+
+__device__ __forceinline__ bool classify_is_heavy(const RenderArgs& a, uint32_t cost)
+{
+  const uint32_t mean = a.counts[3];   // published by the previous classification
+  return a.heavy_x16 != 0u && mean != 0u && (uint64_t)cost * 16u > (uint64_t)mean * a.heavy_x16;
+}
+
+// pre = {packed LIVE, CLEAR, cost}: inclusive wave scans; the wave's totals go to rows 0..2, its cost count to row 3.
+// FB = false (no cost feedback in this launch): two scans, as before the feedback existed; rows 2 and 3 stay zero.
+template <bool FB>
+__device__ __forceinline__ void classify_scan(uint32_t (&pre)[3], bool has_cost, uint32_t (*wave_cnt)[kClassifyThreads / 64], uint32_t lane, uint32_t wave)
+{
+#pragma unroll
+  for(int off = 1; off < 64; off <<= 1)
+#pragma unroll
+    for(int k = 0; k < (FB ? 3 : 2); ++k)
+    {
+      const uint32_t v = __shfl_up(pre[k], off, 64);
+      if(lane >= (uint32_t)off) pre[k] += v;
+    }
+  const uint32_t n_cost = FB ? (uint32_t)__popcll(__ballot(has_cost)) : 0u;
+  if(lane == 63)
+  {
+    wave_cnt[0][wave] = pre[0];
+    wave_cnt[1][wave] = pre[1];
+    wave_cnt[2][wave] = FB ? pre[2] : 0u;
+    wave_cnt[3][wave] = n_cost;
+  }
+}
+
+template <bool FB>
+__device__ __forceinline__ void classify_reserve(const RenderArgs& a, uint32_t (*wave_cnt)[kClassifyThreads / 64], uint32_t* block_base)
+{
+  const uint32_t k = threadIdx.x;
+  if(k < (FB ? (uint32_t)kClassifyRows : 2u))   // no feedback: the NORMAL and the CLEAR list only
+  {
+    const uint32_t row = k == 2u ? 0u : (k >= 3u ? k - 1u : k);   // thread 2 reads row 0 (its high halves), threads 3, 4 rows 2, 3
+    uint32_t sum = 0;
+    for(uint32_t w = 0; w < kClassifyThreads / 64; ++w)
+    {
+      const uint32_t c = wave_cnt[row][w];
+      if(k == 0u) wave_cnt[4][w] = sum;       // exclusive packed prefix over the block's waves
+      else if(k == 1u) wave_cnt[1][w] = sum;  // CLEAR: in place
+      sum += c;
+    }
+    if(k == 0u) sum &= 0xffffu;
+    else if(k == 2u) sum >>= 16;
+    const uint32_t word[kClassifyRows] = {0u, 1u, 3u, 4u, 5u};
+    block_base[k] = sum ? atomicAdd(&a.counters[word[k]], sum) : 0u;
+  }
+}
+
 // One lane per MACRO tile (32×8 pixels: one 128-B line of every first-hit stream per row).
 // A clear macro tile becomes ONE entry of the CLEAR list (written later with full-line
 // dwordx4 stores); any other macro tile contributes its 8×8 tiles to the LIVE list.
 // (Ordering the LIVE list heavy-tiles-first was tried: render +10 %, classify 8 → 26 µs.)
+template <bool FB>
 __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const SceneK scene, const RenderArgs a)
 {
   // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
   // per list per block of macro tiles (a returning atomic on a shared word costs ≈11 ns under
-  // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare).  Lists: 0 = LIVE, 1 = CLEAR.
-  __shared__ uint32_t wave_cnt[2][kClassifyThreads / 64];
-  __shared__ uint32_t block_base[2];
+  // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare).
+  __shared__ uint32_t wave_cnt[kClassifyRows][kClassifyThreads / 64];
+  __shared__ uint32_t block_base[kClassifyRows];
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -667,41 +749,27 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   const bool     clear = valid && a.tile_cull && tile_is_clear<false>(scene, a, tx0 * 8, ty, kMacroTiles * 8);
   const uint32_t nlive = clear ? 0u : ntile;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // cost feedback: what the previous frame's slowest wave spent on this macro tile (read and reset)
+  const uint32_t cost  = FB ? classify_take_cost(a, valid, t) : 0u;
+  const bool     heavy = FB && nlive != 0u && classify_is_heavy(a, cost);
 
-  // wave-level exclusive prefixes of the two counts
-  uint32_t pre[2] = {nlive, clear ? 1u : 0u};
-#pragma unroll
-  for(int off = 1; off < 64; off <<= 1)
-#pragma unroll
-    for(int k = 0; k < 2; ++k)
-    {
-      const uint32_t v = __shfl_up(pre[k], off, 64);
-      if(lane >= (uint32_t)off) pre[k] += v;
-    }
-  if(lane == 63) { wave_cnt[0][wave] = pre[0]; wave_cnt[1][wave] = pre[1]; }
-  pre[0] -= nlive;
+  // wave-level exclusive prefixes of the packed LIVE counts and of the CLEAR count; sum of the costs
+  const uint32_t mine = heavy ? nlive << 16 : nlive;
+  uint32_t pre[3] = {mine, clear ? 1u : 0u, nlive ? cost : 0u};
+  classify_scan<FB>(pre, nlive != 0u && cost != 0u, wave_cnt, lane, wave);
+  pre[0] -= mine;
   pre[1] -= clear ? 1u : 0u;
   __syncthreads();
-  if(threadIdx.x < 2)
-  {
-    uint32_t sum = 0;
-    for(uint32_t w = 0; w < kClassifyThreads / 64; ++w)
-    {
-      const uint32_t c = wave_cnt[threadIdx.x][w];
-      wave_cnt[threadIdx.x][w] = sum;  // exclusive prefix over the block's waves
-      sum += c;
-    }
-    block_base[threadIdx.x] = sum ? atomicAdd(&a.counters[threadIdx.x], sum) : 0u;
-  }
+  classify_reserve<FB>(a, wave_cnt, block_base);
   __syncthreads();
   const unsigned int ticket = classify_ticket(a);
   const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1];
   if(clear && ic < a.cap_clear)
     a.tiles_clear[ic] = tx0 | (ty << 16);
-  const uint32_t il = block_base[0] + wave_cnt[0][wave] + pre[0];
+  const uint32_t il = heavy ? block_base[2] + (wave_cnt[4][wave] >> 16) + (pre[0] >> 16) : block_base[0] + (wave_cnt[4][wave] & 0xffffu) + (pre[0] & 0xffffu);
   for(uint32_t j = 0; j < nlive; ++j)
     if(il + j < a.cap_live)
-      a.tiles_live[il + j] = (tx0 + j) | (ty << 16);
+      a.tiles_live[heavy ? a.cap_live - 1u - (il + j) : il + j] = (tx0 + j) | (ty << 16);
   classify_publish(a, ticket);
 }
 
@@ -715,13 +783,14 @@ constexpr uint32_t kTileMissFlag = 0x80000000u;   // packed entry = tx | ty << 1
 __device__ __forceinline__ uint32_t tile_x(uint32_t packed) { return packed & 0xffffu; }
 __device__ __forceinline__ uint32_t tile_y(uint32_t packed) { return (packed >> 16) & 0x7fffu; }
 
+template <bool FB>
 __global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(const SceneK scene, const RenderArgs a)
 {
   // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
   // per list per block (a returning atomic on a shared word costs ≈11 ns under contention —
-  // MI355X_MICROARCH.md "dequeue" — so they must be rare).  Lists: 0 = LIVE, 1 = CLEAR.
-  __shared__ uint32_t wave_cnt[2][kClassifyThreads / 64];
-  __shared__ uint32_t block_base[2];
+  // MI355X_MICROARCH.md "dequeue" — so they must be rare).
+  __shared__ uint32_t wave_cnt[kClassifyRows][kClassifyThreads / 64];
+  __shared__ uint32_t block_base[kClassifyRows];
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -738,39 +807,27 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(co
   const uint32_t nlive  = (valid && !macro_clear) ? 1u : 0u;
   const uint32_t nclear = (valid && macro_clear && j == 0) ? 1u : 0u;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // cost feedback: the macro tile's previous cost, read (and reset) by its first lane, shared by its four lanes
+  const uint32_t cost  = FB ? (uint32_t)__shfl((int)classify_take_cost(a, j == 0 && ty < tiles_y, m), (int)(lane & ~3u), 64) : 0u;
+  const bool     heavy = FB && nlive != 0u && classify_is_heavy(a, cost);
+  const bool     first = nlive != 0u && j == 0;   // (tile 0 of a macro tile is always inside the image)
 
-  // wave-level exclusive prefixes of the two counts
-  uint32_t pre[2] = {nlive, nclear};
-#pragma unroll
-  for(int off = 1; off < 64; off <<= 1)
-#pragma unroll
-    for(int k = 0; k < 2; ++k)
-    {
-      const uint32_t v = __shfl_up(pre[k], off, 64);
-      if(lane >= (uint32_t)off) pre[k] += v;
-    }
-  if(lane == 63) { wave_cnt[0][wave] = pre[0]; wave_cnt[1][wave] = pre[1]; }
-  pre[0] -= nlive;
+  // wave-level exclusive prefixes of the packed LIVE counts and of the CLEAR count; sum of the costs (once per macro tile)
+  const uint32_t mine = heavy ? nlive << 16 : nlive;
+  uint32_t pre[3] = {mine, nclear, first ? cost : 0u};
+  classify_scan<FB>(pre, first && cost != 0u, wave_cnt, lane, wave);
+  pre[0] -= mine;
   pre[1] -= nclear;
   __syncthreads();
-  if(threadIdx.x < 2)
-  {
-    uint32_t sum = 0;
-    for(uint32_t w = 0; w < kClassifyThreads / 64; ++w)
-    {
-      const uint32_t c = wave_cnt[threadIdx.x][w];
-      wave_cnt[threadIdx.x][w] = sum;  // exclusive prefix over the block's waves
-      sum += c;
-    }
-    block_base[threadIdx.x] = sum ? atomicAdd(&a.counters[threadIdx.x], sum) : 0u;
-  }
+  classify_reserve<FB>(a, wave_cnt, block_base);
   __syncthreads();
   const unsigned int ticket = classify_ticket(a);
-  const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1], il = block_base[0] + wave_cnt[0][wave] + pre[0];
+  const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1];
+  const uint32_t il = heavy ? block_base[2] + (wave_cnt[4][wave] >> 16) + (pre[0] >> 16) : block_base[0] + (wave_cnt[4][wave] & 0xffffu) + (pre[0] & 0xffffu);
   if(nclear && ic < a.cap_clear)
     a.tiles_clear[ic] = tx | (ty << 16);
   if(nlive && il < a.cap_live)
-    a.tiles_live[il] = tx | (ty << 16) | (clear ? kTileMissFlag : 0u);
+    a.tiles_live[heavy ? a.cap_live - 1u - il : il] = tx | (ty << 16) | (clear ? kTileMissFlag : 0u);
   classify_publish(a, ticket);
 }
 
@@ -875,6 +932,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   // list lengths as published by the classification, never beyond the lists' capacity
   const uint32_t n_live  = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)0)), a.cap_live);
   const uint32_t n_clear = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)1)), a.cap_clear);
+  const uint32_t n_heavy = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a.counts, (size_t)2)), n_live);   // live_slot(): they come first
 
   // Queue state.  Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k caches the
   // wave's k-th entry of the current batch of 64 (one gather load per 64 tiles) and entries
@@ -883,7 +941,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   const uint32_t my_live_n  = n_live > g_wave ? (n_live - g_wave + n_waves - 1) / n_waves : 0;   // entries owned
   const uint32_t my_clear_n = n_clear > g_wave ? (n_clear - g_wave + n_waves - 1) / n_waves : 0;
   uint32_t k_live = 0, k_clear = 0;  // next owned entry (wave-uniform)
-  uint32_t live_cache  = lane < my_live_n ? ld1(a.tiles_live, g_wave + (size_t)lane * n_waves) : 0u;
+  uint32_t live_cache  = lane < my_live_n ? ld1(a.tiles_live, live_slot(a.cap_live, n_heavy, g_wave + (uint64_t)lane * n_waves)) : 0u;
   uint32_t clear_cache = lane < my_clear_n ? ld1(a.tiles_clear, g_wave + (size_t)lane * n_waves) : 0u;
   settle_loads(live_cache, clear_cache);
   bool     exhausted = my_live_n == 0;
@@ -1068,7 +1126,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
           {
             if((k_live & 63u) == 0)
             {
-              live_cache = k_live + lane < my_live_n ? ld1(a.tiles_live, g_wave + (size_t)(k_live + lane) * n_waves) : 0u;
+              live_cache = k_live + lane < my_live_n ? ld1(a.tiles_live, live_slot(a.cap_live, n_heavy, g_wave + (uint64_t)(k_live + lane) * n_waves)) : 0u;
               settle_loads(live_cache, clear_cache);
             }
             cur = __builtin_amdgcn_readlane(live_cache, k_live & 63u);
@@ -1163,7 +1221,8 @@ constexpr uint32_t kListedThreads = 256;   // block size of the listed kernel: s
 // counters per lane and run only in the untimed counted pass, the RD instantiations stage RenderedData through LDS:
 // each gets one wave less instead of scratch.
 // RD: the launch exports RenderedData (a.rendered != nullptr); every wave then owns a 4-KB LDS image.
-template <class Real, bool STATS, bool DK, bool RD>
+// FB: the launch takes part in the cost feedback (RenderArgs::tile_cost): heavy tiles first, every traced tile timed.
+template <class Real, bool STATS, bool DK, bool RD, bool FB = false>
 __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64) - (STATS ? 1 : 0) - (RD ? 1 : 0))) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
 {
   __shared__ SceneK     S;
@@ -1177,6 +1236,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
   // for the worst case, one wave per four tiles; ≈15 % of the baseline frame's blocks own nothing)
   const uint32_t n_live  = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a_arg.counts, (size_t)0)), a_arg.cap_live);
   const uint32_t n_clear = umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a_arg.counts, (size_t)1)), a_arg.cap_clear);
+  const uint32_t n_heavy = FB ? umin((uint32_t)__builtin_amdgcn_readfirstlane(ld1(a_arg.counts, (size_t)2)), n_live) : 0u;   // they come first
   if(blockIdx.x * (kListedThreads / 64u) >= (n_live > n_clear ? n_live : n_clear))
   {
     TRT_STAMP(2, wall_clock64());
@@ -1211,7 +1271,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     if((i & 63u) == 0)
     {
       const uint64_t e = entry + (uint64_t)lane * n_waves;
-      live_cache  = e < n_live ? ld1(a.tiles_live, (size_t)e) : 0u;
+      live_cache  = e < n_live ? ld1(a.tiles_live, FB ? live_slot(a.cap_live, n_heavy, e) : (size_t)e) : 0u;
       clear_cache = e < n_clear ? ld1(a.tiles_clear, (size_t)e) : 0u;
       settle_loads(live_cache, clear_cache);
       if(i == 0) TRT_STAMP(1, wall_clock64());
@@ -1231,6 +1291,7 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     if(own_live && !TRT_SKIP(a, 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
+      const unsigned long long tile_t0 = FB ? wall_clock64() : 0ull;
       if(i == 0) TRT_STAMP(4, 0x100000000ull | packed);
       const uint32_t x = tile_x(packed) * 8 + (ln & 7), ly = tile_y(packed) * 8 + (ln >> 3);
       if(RD && (packed & kTileMissFlag))
@@ -1250,6 +1311,13 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
         else
           trace_pixel<Real, DK>(S, a, x, image_row(a, ly), ly, RdSink{RD ? rd_tile + rd_unit(ln & 7, ln >> 3, 0) : nullptr, nullptr},
                                 n_primary, n_bounce, n_shadow, wc);
+      }
+      // cost feedback (RenderArgs::tile_cost): what this wave spent on the tile, kept per macro tile as the maximum over its tiles
+      if(FB && !(packed & kTileMissFlag))
+      {
+        const uint32_t ticks = (uint32_t)(wall_clock64() - tile_t0);
+        if(ln == 0u)
+          atomicMax(&a.tile_cost[tile_y(packed) * ((((a.W + 7u) >> 3) + kMacroTiles - 1u) / kMacroTiles) + tile_x(packed) / kMacroTiles], ticks ? ticks : 1u);
       }
       if(RD && !(packed & kTileMissFlag))
         rd_flush(a, rd_tile, tile_x(packed), tile_y(packed), ln);
@@ -1681,6 +1749,8 @@ Tuning tuning_from_env()
   i32("TRT_FINE_CLASSIFY", t.fine);
   if(getenv("TRT_NO_TILE_CULL")) t.no_tile_cull = 1;
   u32("TRT_DEBUG_SKIP", t.debug_skip);
+  u32("TRT_HEAVY_X16", t.heavy_x16);
+  u32("TRT_HEAVY_MIN_TORI", t.heavy_min_tori);
   if(getenv("TRT_DEBUG_TILES")) t.debug_tiles = 1;
   u64("TRT_PERSIST_BLOCKS", t.persist_blocks);
   u64("TRT_LISTED_BLOCKS", t.listed_blocks);
@@ -1705,12 +1775,13 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
     // 1. classify the tiles into the LIVE and CLEAR lists (one lane per macro tile, or per 8×8 tile when a.fine)
     const uint64_t macros = (uint64_t)(((a.W + 7) / 8 + kMacroTiles - 1) / kMacroTiles) * ((a.n_local_rows + 7) / 8);
     const uint64_t lanes  = a.fine ? macros * kMacroTiles : macros;
-    if(a.fine)
-      hipLaunchKernelGGL(tile_classify_fine_kernel, dim3((uint32_t)((lanes + kClassifyThreads - 1) / kClassifyThreads)),
-                         dim3(kClassifyThreads), 0, stream, scene, a);
-    else
-      hipLaunchKernelGGL(tile_classify_kernel, dim3((uint32_t)((lanes + kClassifyThreads - 1) / kClassifyThreads)),
-                         dim3(kClassifyThreads), 0, stream, scene, a);
+    // cost feedback: the plain listed kernels only (the counted and the alternative-solver instantiations go without)
+    const bool fb = v == kRenderListed && a.tile_cost != nullptr && a.heavy_x16 != 0u && a.stats == nullptr && !scene.dk;
+    const dim3 cgrid((uint32_t)((lanes + kClassifyThreads - 1) / kClassifyThreads));
+    if(a.fine && fb) hipLaunchKernelGGL(tile_classify_fine_kernel<true>, cgrid, dim3(kClassifyThreads), 0, stream, scene, a);
+    else if(a.fine) hipLaunchKernelGGL(tile_classify_fine_kernel<false>, cgrid, dim3(kClassifyThreads), 0, stream, scene, a);
+    else if(fb) hipLaunchKernelGGL(tile_classify_kernel<true>, cgrid, dim3(kClassifyThreads), 0, stream, scene, a);
+    else hipLaunchKernelGGL(tile_classify_kernel<false>, cgrid, dim3(kClassifyThreads), 0, stream, scene, a);
     // 2. resident grid: kPersistentBlocksPerCU blocks of 4 waves per CU, never more waves than tiles
     uint64_t cap = (uint64_t)n_cus * kPersistentBlocksPerCU;
     if(tn.persist_blocks) cap = tn.persist_blocks;
@@ -1726,7 +1797,9 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
       const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
 #define TRT_LAUNCH_LISTED(REAL, DK_)                                                                                   \
   do {                                                                                                                 \
-    if(a.rendered && a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, DK_, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);  \
+    if(fb && a.rendered) hipLaunchKernelGGL((render_listed_kernel<REAL, false, false, true, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);  \
+    else if(fb) hipLaunchKernelGGL((render_listed_kernel<REAL, false, false, false, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);      \
+    else if(a.rendered && a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, DK_, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);  \
     else if(a.rendered) hipLaunchKernelGGL((render_listed_kernel<REAL, false, DK_, true>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);       \
     else if(a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, DK_, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);          \
     else hipLaunchKernelGGL((render_listed_kernel<REAL, false, DK_, false>), dim3(lgrid), dim3(bthreads), 0, stream, scene, a);                     \

@@ -30,9 +30,17 @@ struct RenderArgs {
                                     // Zero between frames: the LAST classification block of a frame publishes the
                                     // totals to `counts` and resets them (no memset, no double buffering: a frame
                                     // depends on no other frame, eager or replayed from a hipGraph)
-  unsigned int*       counts;       // [0] = #LIVE tiles, [1] = #CLEAR macro tiles of this frame (written, never added to)
+  unsigned int*       counts;       // [0] = #LIVE tiles, [1] = #CLEAR macro tiles of this frame (written, never added to);
+                                    // [2] = how many of the LIVE tiles are HEAVY, [3] = mean cost of the previous frame's traced macro tiles
   uint32_t*           tiles_live;   // tiles that need ray tracing
   uint32_t*           tiles_clear;  // macro tiles whose every pixel provably misses
+  // Cost feedback: the listed kernel leaves the time (100-MHz ticks) its slowest wave spent on each traced macro tile; the
+  // next classification reads and resets it, calls a macro tile HEAVY when that exceeds heavy_x16/16 × the previous mean,
+  // and stores the HEAVY tiles downwards from the END of tiles_live: logical entry L < #HEAVY is tiles_live[cap_live-1-L],
+  // any other one tiles_live[L - #HEAVY] — the render kernels start with the heavy tiles.  Scheduling only: no result
+  // depends on the order of the list, and a frame without history (or heavy_x16 == 0) has no heavy tiles.
+  uint32_t*           tile_cost;    // [macro tiles of the launch] or nullptr
+  uint32_t            heavy_x16;
   uint32_t            cap_live;     // capacity of tiles_live / tiles_clear in entries: nothing indexes past them
   uint32_t            cap_clear;
   uint32_t            min_batch;    // persistent kernel: lanes needed to run a shader/refill round (default 24)
@@ -50,6 +58,8 @@ struct Tuning {
   int      no_tile_cull       = 0;    // TRT_NO_TILE_CULL
   uint32_t debug_skip         = 0;    // TRT_DEBUG_SKIP (timing ablations: the frame is then INCOMPLETE)
   int      debug_tiles        = 0;    // TRT_DEBUG_TILES: print the list lengths after every frame (synchronises)
+  uint32_t heavy_x16          = 24;   // TRT_HEAVY_X16: a macro tile is HEAVY above heavy_x16/16 (1.5) x the mean cost; 0 = no cost feedback
+  uint32_t heavy_min_tori     = 2;    // TRT_HEAVY_MIN_TORI: cost feedback only for scenes with at least this many tori (below)
   uint64_t persist_blocks     = 0;    // TRT_PERSIST_BLOCKS   (0 = default)
   uint64_t listed_blocks      = 0;    // TRT_LISTED_BLOCKS
   int      static_tile        = 8;    // TRT_TILE
