@@ -190,6 +190,9 @@ int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt
  * scratch, or to upload the tables of a new toroidal-camera frame, while `stream` is being captured
  * returns TRT_E_INVALID instead of allocating inside the capture.  Scratch that a later, larger call
  * replaces stays allocated until trt_destroy, so graphs captured before keep replaying correctly.
+ * The only thing a frame leaves behind in the ctx is a scheduling hint: for scenes of two or more tori the
+ * time its slowest wave spent on each traced tile, which the next frame uses to start the heavy tiles
+ * first.  No output bit depends on it (first frame, replay, camera cut: same images, same counts).
  *
  * Rows [row_begin,row_end) only; outputs are indexed relative to the FULL image, so a
  * rank that owns a row band passes pointers to the full-frame buffers (or to buffers
