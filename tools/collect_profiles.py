@@ -45,10 +45,10 @@ fetch = write = 0.0
 # (with / without query counters): take the one the timed steps use (most launches)
 # the headline frame = tile_classify_kernel + the plain FP32 instantiation of the variant's render kernel (the PMC passes
 # also run bench.py's secondary configurations: FP64, RenderedData, persistent … — not part of the headline traffic)
-want = {"listed": "render_listed_kernel<float, false, false, false>", "persistent": "render_persistent_kernel<float>",
+want = {"listed": "render_listed_kernel<float, false, false, false, false>", "persistent": "render_persistent_kernel<float>",
         "static": "render_static_kernel<float, 8, false>"}[variant]
 for k, d in summary.items():
-    if want in k or k.endswith("tile_classify_kernel"):
+    if want in k or k.endswith("tile_classify_kernel<false>"):
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md §HBM: FETCH_SIZE
         # tallies 128-B read requests at 64 B, so wide coalesced reads count HALF -> doubled here;
         # WRITE_SIZE is exact for 16-B-per-lane streaming stores (this kernel's dominant stores).
