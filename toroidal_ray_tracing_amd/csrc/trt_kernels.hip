@@ -617,26 +617,35 @@ __device__ __forceinline__ unsigned int classify_ticket(const RenderArgs& a)
 
 __device__ __forceinline__ void classify_publish(const RenderArgs& a, unsigned int ticket)
 {
-  if(threadIdx.x == 0)
+  if(threadIdx.x < 64u)   // the block's first wave: thread 0 holds the ticket, lanes 0…4 fetch the five accumulators at once
   {
-    const unsigned int shard = blockIdx.x & 7u, in_shard = (gridDim.x - shard + 7u) >> 3, n_shards = gridDim.x < 8u ? gridDim.x : 8u;
-    bool last = false;
-    if(ticket == in_shard - 1)
+    int last = 0;
+    if(threadIdx.x == 0)
     {
-      atomicExch(&a.counters[8u + shard], 0u);
-      last = atomicAdd(&a.counters[2], 1u) == n_shards - 1;
+      const unsigned int shard = blockIdx.x & 7u, in_shard = (gridDim.x - shard + 7u) >> 3, n_shards = gridDim.x < 8u ? gridDim.x : 8u;
+      if(ticket == in_shard - 1)
+      {
+        atomicExch(&a.counters[8u + shard], 0u);
+        last = atomicAdd(&a.counters[2], 1u) == n_shards - 1 ? 1 : 0;
+      }
     }
+    last = __shfl(last, 0, 64);
     if(last)
     {
-      const unsigned int n_norm = atomicExch(&a.counters[0], 0u), n_clear = atomicExch(&a.counters[1], 0u);
-      const unsigned int n_heavy = atomicExch(&a.counters[3], 0u);
-      const unsigned int cost_sum = atomicExch(&a.counters[4], 0u), cost_cnt = atomicExch(&a.counters[5], 0u);
-      const unsigned int n_live = n_norm + n_heavy < a.cap_live ? n_norm + n_heavy : a.cap_live;   // (their sum never exceeds the tiles)
-      a.counts[0] = n_live;
-      a.counts[1] = n_clear < a.cap_clear ? n_clear : a.cap_clear;
-      a.counts[2] = n_heavy < n_live ? n_heavy : n_live;
-      a.counts[3] = cost_cnt ? cost_sum / cost_cnt : 0u;   // the threshold of the NEXT frame's classification
-      atomicExch(&a.counters[2], 0u);
+      // (five exchanges in ONE instruction instead of five dependent round trips at the very end of the kernel)
+      const uint32_t word = threadIdx.x < 2u ? threadIdx.x : threadIdx.x + 1u;   // counters 0, 1, 3, 4, 5
+      const uint32_t v = threadIdx.x < 5u ? atomicExch(&a.counters[word], 0u) : 0u;
+      const unsigned int n_norm = __shfl(v, 0, 64), n_clear = __shfl(v, 1, 64), n_heavy = __shfl(v, 2, 64);
+      const unsigned int cost_sum = __shfl(v, 3, 64), cost_cnt = __shfl(v, 4, 64);
+      if(threadIdx.x == 0)
+      {
+        const unsigned int n_live = n_norm + n_heavy < a.cap_live ? n_norm + n_heavy : a.cap_live;   // (their sum never exceeds the tiles)
+        a.counts[0] = n_live;
+        a.counts[1] = n_clear < a.cap_clear ? n_clear : a.cap_clear;
+        a.counts[2] = n_heavy < n_live ? n_heavy : n_live;
+        a.counts[3] = cost_cnt ? cost_sum / cost_cnt : 0u;   // the threshold of the NEXT frame's classification
+        atomicExch(&a.counters[2], 0u);
+      }
     }
   }
 }
