@@ -24,14 +24,17 @@ for k in range(n):
     solver = [abi.TRT_SOLVE_F32, abi.TRT_SOLVE_F64, abi.TRT_SOLVE_FERRARI_F32][int(rng.integers(0, 3))]
     if variant == "persistent" and solver == abi.TRT_SOLVE_FERRARI_F32:
         solver = abi.TRT_SOLVE_F32
-    t.set_render_variant(variant); t.set_solver(solver); t.set_classification(int(rng.integers(-1, 2))); t.enable_stats(True)
+    counted = bool(rng.integers(0, 2))   # the uncounted listed frames of multi-torus scenes take part in the cost feedback (stale costs
+    t.set_render_variant(variant); t.set_solver(solver); t.set_classification(int(rng.integers(-1, 2))); t.enable_stats(counted)   # of OTHER scenes)
     rgba, hits = t.render(sc, g, pc, W, H, cam)
-    st = t.stats()
+    if k % 3 == 0:   # the same frame again: now with ITS OWN history, if it is one that keeps one
+        rgba, hits = t.render(sc, g, pc, W, H, cam)
+    st = t.stats() if counted else None
     wr, wh, _, wst = oracle.render(sc, g, pc, W, H, cam, precision=solver, nthreads=16)
     try:
         assert_hits_equal(hits, wh, f"seed {first + k} ({variant}, solver {solver}, {W}x{H}, cam {cam})")
         np.testing.assert_allclose(rgba, wr, rtol=COLOR_RTOL, atol=COLOR_ATOL)
-        assert q(st) == q(wst), (q(st), q(wst))
+        assert st is None or q(st) == q(wst), (q(st), q(wst))
     except AssertionError as e:
         bad += 1
         print(f"MISMATCH seed {first + k}: {str(e)[:300]}", flush=True)
