@@ -3,6 +3,11 @@
 //   trace_kernel              trace(rays_in → hits_out): SoA rays in, closest hit out.
 //   render_static_kernel      one lane per pixel, 8×8 pixel tile per wavefront; each lane runs the
 //                             reference's raygen bounce loop (REFL/shaders/raytrace.rgen:62-85).
+//   tile_classify[_fine]_kernel  which 8×8 tiles can be answered without tracing a ray: the CLEAR list (32×8 macro tiles,
+//                             constant fills) and the LIVE list (heavy tiles of the previous frame first: cost feedback).
+//   render_listed_kernel      the DEFAULT render kernel: a wave takes its entries of both lists — CLEAR macro tiles as
+//                             non-temporal full-line fills, LIVE tiles traced per pixel like the static kernel — so the
+//                             store-bound part of the frame drains behind the compute-bound part.
 //   render_persistent_kernel  persistent wavefronts over a global work queue: the bounce
 //                             loop is flattened into per-lane queries (closest-hit, shadow,
 //                             bounce); a lane whose pixel is finished is refilled at once
@@ -11,7 +16,8 @@
 //                             ray–torus tests.
 //
 // One lane = one ray.  Scene constants are staged into LDS once per block.  No MFMA: the
-// work is scalar FP32/FP64 root finding.  Compiled with -ffp-contract=off (see
+// work is scalar FP32/FP64 root finding.  post_kernel (tonemap) and the splat_* kernels (point-cloud re-projection) serve the
+// callers either side of the path.  Compiled with -ffp-contract=off (see
 // trt_device.hpp for the arithmetic contract).  Every kernel is instantiated for the FP32
 // and the FP64 root solve (BASELINE config 4); I/O is FP32 in both.
 #include "trt_kernels.hpp"
