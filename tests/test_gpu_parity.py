@@ -801,6 +801,28 @@ def test_cost_feedback_orders_tiles_and_changes_nothing():
         for k in range(2):
             got, _ = frame(sc8, 1024, 768)
             assert same(ref64, got)
+        # the feedback is device state like any other: three frames captured into ONE hipGraph (every frame orders its tiles
+        # by the frame before, also across replays) reproduce the eager frame, replay after replay
+        t.set_solver(abi.TRT_SOLVE_F32)
+        t.enable_stats(False)
+        W, H = 1024, 768
+        g, pc = camera.baseline_camera(W, H), camera.baseline_push(5)
+        outs = [torch.full((H, W, 4), -3.0, device=dev) for _ in range(3)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            t.render_dev(sc8, g, pc, W, H, outs[0].data_ptr(), stream=side.cuda_stream)   # scratch sized outside the capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for o in outs:
+                    t.render_dev(sc8, g, pc, W, H, o.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            for _ in range(3):
+                for o in outs:
+                    o.fill_(-3.0)
+                graph.replay()
+                side.synchronize()
+                assert all(torch.equal(o.view(torch.int32), ref[0].view(torch.int32)) for o in outs)
+        torch.cuda.current_stream().wait_stream(side)
     finally:
         t.close()
 
