@@ -101,3 +101,15 @@ def test_reproject_example_consumes_a_capture(tmp_path):
     assert img.shape == (128 * 96, 3) and abs(int((img[:, :2] != 0.8).any(axis=1).sum()) - covered) <= 2   # 6-digit text
     raw = (tmp_path / "data" / "torusptCloudImage_10.ppm").read_bytes()
     assert raw.startswith(b"P6\n128 96\n255\n") and len(raw) == len(b"P6\n128 96\n255\n") + 128 * 96 * 3
+
+
+def test_frames_in_flight_example():
+    """examples/frames_in_flight (plain C ABI): three contexts on three streams render the same frame of the eight nested tori
+    (FP64 solve) alternately; the program compares their images bit for bit and exits non-zero if they differ."""
+    exe = os.path.join(ROOT, "examples", "frames_in_flight")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe, "3", "9", "320", "1", "1"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "images of the 3 contexts identical" in p.stdout and p.stdout.count("in flight:") == 3
+    p = subprocess.run([exe, "2", "4", "200", "0", "0"], capture_output=True, text=True)    # one torus, FP32
+    assert p.returncode == 0 and "identical" in p.stdout
