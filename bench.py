@@ -26,16 +26,27 @@ and build + walk a quartic, `traced_tests_per_s` the tests a lane executed at al
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (a parent process that makes no GPU
 call runs `torch.distributed.run` and relays rank 0's JSON line); launched BY torch.distributed.run
 (RANK/WORLD_SIZE in the environment) it is one of the ranks.  The SAME 4096² frames are tiled across
-the ranks in interleaved groups of rows, and the rgba32f framebuffer of the frame that leaves the loop —
-the last frame of every step, as the reference reads its image back once per 60-frame batch
-(BEF/main.cpp:339-343, 384-399) — is all-gathered over RCCL/xGMI inside the timed step, as BASELINE.json
-north_star prescribes → "scaling": "strong".  `--gather-every 1` replicates EVERY frame on every GPU
-(link-bound by two orders of magnitude); `gather_ms` and `render_only_primary_tests_per_s`
-in the N > 1 line say what a gather and the sharded renders cost on their own.
+the ranks in interleaved groups of rows → "scaling": "strong".  `value` of the N > 1 line is the cadence
+"gather once per step": the rgba32f framebuffer of the frame that leaves the loop — the last frame of every
+step, as the reference reads its image back once per 60-frame batch (BEF/main.cpp:339-343, 384-399) — is
+all-gathered over RCCL/xGMI inside the timed step; the cadence is named in `metric` and in `gather_cadence`.
+The same line carries the OTHER cadence too, measured in the same job right after the headline loop:
+`value_gather_every_frame` = {"rgba8": …, "fp32": …}, every frame replicated on every GPU (what the
+reference's loop does when it presents each frame, REFL/main.cpp:298-313; link-bound) — the
+figure that is like-for-like with round 1's N > 1 line.  `gather_ms` and `render_only_primary_tests_per_s`
+say what a gather and the sharded renders cost on their own.  A rank's step of F frames × K streams is
+captured once into a hipGraph and replayed (`--no-graph`: eager launches).
+
+Roofline (N = 1): the timed loop writes every frame into the same buffers — the reference's situation, one
+offscreen image — and part of what a frame leaves in the 256-MB Infinity Cache is overwritten there by the
+next one.  `roofline` is therefore priced on a second pass of the same frames into FOUR alternating output
+sets (3 GB: nothing is re-written while it is still cached — the fraction HBM actually served), timed with
+HIP events like the first; the single-image figure stays beside it as `roofline.frac_cached`.
+`--output-sets 4` makes the timed loop itself alternate (what tools/make_profiles.sh runs under rocprofv3).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-step F]
                        [--variant listed|persistent|static] [--gather fp32|rgba8|none] [--gather-every step|K]
-                       [--no-cpu-baseline] [--no-secondary] [--size 4096] [--depth 5]
+                       [--no-cpu-baseline] [--no-secondary] [--size 4096] [--depth 5] [--output-sets M] [--no-graph]
 """
 import argparse
 import ctypes as C
@@ -95,6 +106,13 @@ def parse():
                     help="no GPU, no measurement: every rank fills its rows with a rank pattern, the gather runs, "
                          "rank 0 prints a line with value null (tests/test_distributed.py)")
     ap.add_argument("--center", default="0,0,0", help="camera look-at point (diagnostics; default = BASELINE)")
+    ap.add_argument("--output-sets", type=int, default=1,
+                    help="output sets the timed loop rotates over (default 1: one offscreen image, like the reference; 4: no "
+                         "Infinity-Cache reuse between frames — the roofline pass always uses 4)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N>1: launch every frame eagerly instead of replaying the step's hipGraph")
+    ap.add_argument("--no-other-cadence", action="store_true",
+                    help="N>1: skip the second measurement (a gather after EVERY frame, rgba8 and fp32)")
     return ap.parse_args()
 
 
@@ -304,25 +322,6 @@ def secondary(tr, dev, stream):
                 camera.baseline_push(5), solver=abi.TRT_SOLVE_F64)
     render_case("C3 with the persistent-threads variant", camera.single_torus_scene(), camera.baseline_camera(W, W),
                 camera.baseline_push(5), variant="persistent")
-    # the headline frame into FOUR alternating output sets (3 GB): the headline — like the reference's frame loop — writes
-    # every frame into the same buffers, and what a frame left in the 256-MB Infinity Cache is overwritten there by the
-    # next; this entry is the same frame without that reuse (regime 1)
-    sets = [(torch.empty(W, W, 4, device=dev), {k: torch.empty(n, device=dev) for k in hits}) for _ in range(3)]
-    ptrs = [(rgba.data_ptr(), hp)] + [(r.data_ptr(), {k: v.data_ptr() for k, v in h.items()}) for r, h in sets]
-    sc3, g3, pc3, turn = camera.single_torus_scene(), camera.baseline_camera(W, W), camera.baseline_push(5), [0]
-
-    def alternating():
-        r, h = ptrs[turn[0] & 3]
-        turn[0] += 1
-        tr.render_dev(sc3, g3, pc3, W, W, r, hit_ptrs=h, stream=s)
-
-    for _ in range(8):
-        alternating()
-    ms = timeit(alternating, reps=12)
-    res.append({"name": "C3 into four alternating output sets (no Infinity-Cache reuse between frames)", "ms": ms, "units": n,
-                "GB_per_s": BYTES_PER_PIXEL * n / ms / 1e6, "frac_hbm": BYTES_PER_PIXEL * n / ms / 1e6 / HBM_PEAK_GBPS, "dtype": "f32",
-                "bound": "hbm", "kernel": "classify + render_listed_kernel", "primary_tests_per_s": n / ms * 1e3})
-    del sets, ptrs
     # the namesake capture: toroidal camera inside an R=6 torus, 4096x2048, RenderedData exported
     Wc, Hc = 4096, 2048
     rend = torch.empty(Wc * Hc, 16, device=dev)
@@ -450,26 +449,83 @@ def worker(a, world, rank, local):
     g = camera.baseline_camera(W, H) if a.center == "0,0,0" else camera.globals_for(
         (0.0, 1.5, -4.0), tuple(float(v) for v in a.center.split(",")), W, H)
     pc = camera.baseline_push(a.depth)
-    n_streams = a.streams if a.streams > 0 else (4 if world > 1 else 1)
+    gather_every = F if a.gather_every == "step" else max(1, int(a.gather_every))
+    # frames in flight: 4 streams for the 1/N parts of N > 1 (one does not fill the chip), ONE for the full frame — and one
+    # when every frame is gathered: the render is then timed with an event pair per frame, which concurrent frames on
+    # other streams would stretch (each pair would include the contention of up to K frames)
+    n_streams = a.streams if a.streams > 0 else (4 if world > 1 and gather_every != 1 else 1)
     trs = [Tracer(local) for _ in range(n_streams)]
     tr = trs[0]
     if a.variant:
         for t_ in trs:
             t_.set_render_variant(a.variant)
     variant = tr.render_variant()
-
-    gather_every = F if a.gather_every == "step" else max(1, int(a.gather_every))
-    frame = trtd.TiledFrame(trs, W, H, world, rank, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else (),
-                            gather=a.gather, group_rows=a.group_rows or None, gather_every=gather_every,
-                            force_collective=a.rehearse_collective)
+    want_hits = ("t", "px", "py", "pz", "nx", "ny", "nz") if a.hits == "tpn" else ()
     stream = torch.cuda.current_stream()
 
-    def one_frame(ev=None):
-        frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, stream, events=ev)
+    def sync_all():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(frame, steps, warmup, use_graph):
+        """`warmup` untimed steps, then EXACTLY `steps` steps of F frames between two barrier + synchronize brackets.
+        Returns (wall seconds, max over ranks; HIP-event milliseconds of the render launches per frame, this rank)."""
+        def one_frame(ev=None):
+            frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, stream, events=ev)
+
+        frame.restart()   # the gathers fall on the last frame of every step from here on
+        graphed = False
+        if use_graph:
+            for _ in range(frame.n_sets):   # every context sized, every output set touched, before anything is captured
+                one_frame()
+            frame.restart()
+            try:
+                frame.capture_step(sc, g, pc, abi.TRT_CAMERA_PINHOLE, stream, F)
+                graphed = True
+            except Exception as e:   # a step that cannot be captured is launched eagerly — and the line says so
+                print(f"[bench] rank {rank}: step not captured ({e}); eager launches", file=sys.stderr)
+        for _ in range(warmup):
+            if graphed:
+                frame.step(stream)
+            else:
+                for _ in range(F):
+                    one_frame()
+        frame.finish()
+        # HIP events on the launch stream (torch's current stream IS the stream handed to trt_render*_dev, and the stream a
+        # graph is replayed on).  One pair around each step's F frames; with a gather after EVERY frame a pair around every
+        # frame's render launches instead, because the stream then also carries the waits on the gathers.
+        per_frame = multi and frame.gather and frame.gather_every == 1 and not graphed
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(steps * (F if per_frame else 1))]
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if not per_frame:
+                evs[k][0].record(stream)
+            if graphed:
+                frame.step(stream)
+            else:
+                for f in range(F):
+                    one_frame(evs[k * F + f] if per_frame else None)
+            if not per_frame:
+                frame.join(stream)   # several render streams: `stream` continues behind all of them (a no-op with one)
+                evs[k][1].record(stream)
+        frame.finish()   # N > 1: the last frames' all-gathers are part of the K steps
+        sync_all()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if multi:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), sum(e0.elapsed_time(e1) for e0, e1 in evs) / (steps * F), graphed
+
+    frame = trtd.TiledFrame(trs, W, H, world, rank, dev, want_hits=want_hits, gather=a.gather, group_rows=a.group_rows or None,
+                            gather_every=gather_every, force_collective=a.rehearse_collective, output_sets=a.output_sets)
 
     # one counted pass (untimed): how many ray–torus tests one frame executes
     tr.enable_stats(True)
-    one_frame()
+    frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, stream)
     frame.finish()
     torch.cuda.synchronize()
     st = tr.stats()
@@ -479,58 +535,56 @@ def worker(a, world, rank, local):
     if multi:
         dist.all_reduce(tests)
     cnt = dict(zip(keys, (int(v) for v in tests.tolist())))
-    if not os.environ.get("TRT_DEBUG_SKIP"):   # a timing ablation of the tuning build renders part of the frame only
-        assert cnt["pixels"] == W * H and cnt["primary_tests"] == W * H * sc.n_tori
+    assert cnt["pixels"] == W * H and cnt["primary_tests"] == W * H * sc.n_tori, cnt
 
-    frame.restart()   # the gathers fall on the last frame of every step from here on
-    for _ in range(a.warmup):
-        for _ in range(F):
-            one_frame()
-    frame.finish()
-    # HIP events on the launch stream (torch's current stream IS the stream handed to trt_render*_dev).
-    # One pair around each step's F back-to-back frames; with a gather after EVERY frame (--gather-every 1) a pair around
-    # every frame's render launches instead, because the stream then also carries the waits on the gathers.
-    per_frame = multi and frame.gather and gather_every == 1
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(a.steps * (F if per_frame else 1))]
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        if not per_frame:
-            evs[k][0].record(stream)
-        for f in range(F):
-            one_frame(evs[k * F + f] if per_frame else None)
-        if not per_frame:
-            frame.join(stream)   # several render streams: `stream` continues behind all of them (a no-op with one)
-            evs[k][1].record(stream)
-    frame.finish()   # N > 1: the last frames' all-gathers are part of the K steps
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if multi:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    # the step of a 1/N part is captured into a hipGraph (launch-bound otherwise); the full frame of N = 1 is not
+    use_graph = multi and not a.no_graph and (gather_every % F == 0 or not frame.gather) and F % frame.n_sets == 0
+    dt, kern_ms, graphed = measure(frame, a.steps, a.warmup, use_graph)
     n_frames = a.steps * F
 
+    def fractions(ms, st_):
+        ach = BYTES_PER_PIXEL * frame.local_pixels / (ms * 1e-3) / 1e9
+        fl = (FLOP_PER_TRACED * st_["traced_tests"] + FLOP_PER_SOLVED * st_["solved_tests"] + FLOP_PER_EVAL * st_["evaluations"])
+        tf = fl / (ms * 1e-3) / 1e12
+        return ach, fl, tf, ach / HBM_PEAK_GBPS, tf / FP32_PEAK_TFLOPS
+
     # dominant kernel(s) of one frame: classification + render kernel, timed live with HIP events
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / n_frames
     px_per_launch = frame.local_pixels
-    achieved = BYTES_PER_PIXEL * px_per_launch / (kern_ms * 1e-3) / 1e9
-    flop_frame = (FLOP_PER_TRACED * st["traced_tests"] + FLOP_PER_SOLVED * st["solved_tests"] + FLOP_PER_EVAL * st["evaluations"])
-    tflops = flop_frame / (kern_ms * 1e-3) / 1e12
-    frac_hbm, frac_valu = achieved / HBM_PEAK_GBPS, tflops / FP32_PEAK_TFLOPS
+    achieved, flop_frame, tflops, frac_hbm, frac_valu = fractions(kern_ms, st)
+
+    # N = 1, roofline pass: the same frames into FOUR alternating output sets — nothing a frame wrote is still in the
+    # Infinity Cache when it is written again, so this is the fraction HBM served (the single-image figure above is kept
+    # as frac_cached).  Skipped when the timed loop itself alternated (--output-sets >= 4).
+    cached = None
+    if not multi and frame.n_sets < 4:
+        cached = {"kernel_ms": kern_ms, "achieved": achieved, "frac": frac_hbm}
+        alt = trtd.TiledFrame(trs, W, H, world, rank, dev, want_hits=want_hits, gather="none", output_sets=4)
+        _, kern_ms, _ = measure(alt, min(a.steps, 10), 1, False)
+        achieved, flop_frame, tflops, frac_hbm, frac_valu = fractions(kern_ms, st)
+        del alt
 
     # N > 1: the slowest rank's render time per frame — what the sharded path alone delivers (no collective)
     kmax = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
     if multi:
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     kern_ms_max = float(kmax.item())
+
+    # N > 1, the OTHER cadence, measured in the same job: a gather after EVERY frame (rgba8: the 8-bit image a swapchain
+    # presents; fp32: the rgba32f framebuffer — round 1's N > 1 line).  A few steps each: these are link-bound.
+    other = None
+    if multi and frame.gather and gather_every != 1 and not a.no_other_cadence:
+        other = {}
+        for mode in ("rgba8", "fp32"):
+            try:
+                fr = trtd.TiledFrame(trs, W, H, world, rank, dev, want_hits=want_hits, gather=mode, group_rows=a.group_rows or None,
+                                     gather_every=1, force_collective=a.rehearse_collective)
+                dto, _, _ = measure(fr, max(1, min(a.steps, 3)), 1, False)
+                other[mode] = {"value": max(1, min(a.steps, 3)) * F * cnt["primary_tests"] / dto, "unit": "primary ray-torus tests/s",
+                               "ms_per_frame": dto / (max(1, min(a.steps, 3)) * F) * 1e3, "steps": max(1, min(a.steps, 3)),
+                               "tiling": fr.describe()}
+                del fr
+            except Exception as e:   # never let the second measurement cost the headline line
+                other[mode] = {"error": repr(e)}
 
     # N > 1, diagnostics only (outside the timed region): the collectives of one frame alone, so that the
     # line shows what binds the step — the rank-local render (roofline.kernel_ms) or replicating the framebuffer
@@ -555,23 +609,31 @@ def worker(a, world, rank, local):
     # kernel sources it was measured on (sha256 written by make_profiles.sh ON the GPU box): other sources, or another
     # size / depth, yield null, not an old number.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
-    if os.path.exists(tpath):
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("trt_kernels.hip", "trt_device.hpp", "trt_kernels.hpp", "trt_api.hip"):
+        h.update(open(os.path.join(ROOT, "toroidal_ray_tracing_amd", "csrc", f), "rb").read())
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):   # newest round first
         try:
             tj = json.load(open(tpath))
-            import hashlib
-            h = hashlib.sha256()
-            for f in ("trt_kernels.hip", "trt_device.hpp", "trt_kernels.hpp", "trt_api.hip"):
-                h.update(open(os.path.join(ROOT, "toroidal_ray_tracing_amd", "csrc", f), "rb").read())
             if tj.get("size") == a.size and tj.get("depth") == a.depth and tj.get("kernel_sources_sha256") == h.hexdigest():
                 traffic = tj.get(variant, {}).get("hbm_bytes_per_launch")
+                break
         except Exception:
-            traffic = None
+            continue
 
     if rank == 0:
         value = n_frames * cnt["primary_tests"] / dt
+        cadence = None
+        if multi and frame.gather:
+            cadence = ("framebuffer all-gathered after EVERY frame" if gather_every == 1 else
+                       f"framebuffer all-gathered once per step of {F} frames" if gather_every == F else
+                       f"framebuffer all-gathered every {gather_every} frames") + f" ({frame.mode})"
+        elif multi:
+            cadence = "no gather (rank-local renders only)"
         out = {
-            "metric": "ray-torus intersections/sec at 4096^2 x 4 bounces (primary tests/s)",
+            "metric": "ray-torus intersections/sec at 4096^2 x 4 bounces (primary tests/s)" + (f"; {cadence}" if cadence else ""),
             "value": value, "unit": "primary ray-torus tests/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -590,25 +652,38 @@ def worker(a, world, rank, local):
                       "model": f"{FLOP_PER_TRACED}/traced test + {FLOP_PER_SOLVED}/solved test + {FLOP_PER_EVAL}/evaluation of (f,f'); "
                                "fma = 2; ray generation, normals and shading not counted"},
             "gather_ms": gather_ms,
+            # N > 1: WHEN the framebuffer is replicated is part of what `value` means — named here and in `metric`.
+            # `value` = the cadence of `gather_cadence`; `value_gather_every_frame` = the other one, measured in the same job
+            # (every frame replicated on every GPU: rgba8 = the image a swapchain presents, fp32 = the rgba32f framebuffer)
+            "gather_cadence": cadence,
             "gather_every_frames": (gather_every if frame.gather else None),
+            "value_gather_every_frame": other,
+            "step_launch": ("one hipGraph replay per step" if graphed else "eager launches"),
             "rehearse_collective": bool(a.rehearse_collective),
             "frames_in_flight": n_streams,
-            # the rank-local renders alone (max over ranks of the HIP-event render time per frame): the part of the path that
-            # shards; `value` above includes replicating the framebuffer on every GPU, as north_star prescribes
+            "output_sets": frame.n_sets,
+            # the rank-local renders alone (max over ranks of the HIP-event render time per frame): the part of the path that shards
             "render_only_primary_tests_per_s": cnt["primary_tests"] / (kern_ms_max * 1e-3) if multi else None,
             "target_primary_tests_per_s": 2.0e9,
-            "roofline": {"bound": "hbm" if frac_hbm >= frac_valu else "mfma", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm" if frac_hbm >= frac_valu else "valu", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": frac_hbm, "traffic": traffic,
                          "frac_valu": frac_valu,
                          "kernel": (f"render_{variant}_kernel" if variant == "static"
                                     else f"tile_classify_kernel + render_{variant}_kernel (one frame)"),
                          "kernel_ms": kern_ms,
+                         "output_sets": 4 if cached else frame.n_sets,
+                         # the same frame written into ONE output set (the timed loop of `value`, the reference's one offscreen
+                         # image): lines still in the 256-MB Infinity Cache are overwritten there, so this exceeds what HBM served
+                         "frac_cached": cached["frac"] if cached else None,
+                         "achieved_cached": cached["achieved"] if cached else None,
+                         "kernel_ms_cached": cached["kernel_ms"] if cached else None,
                          "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL, "pixels_per_launch": px_per_launch,
-                         "note": "what binds: the HBM fraction exceeds the FP32-VALU fraction by an order of magnitude, so the frame is priced "
-                                 "against HBM; it is a mixture — ~85 % of the pixels are constant fills at the store ceiling, the rest is "
-                                 "latency-bound root finding; every frame is written into the same buffers (one offscreen image, as in the "
-                                 "reference): lines of the traced tiles still in the 256-MB Infinity Cache are overwritten there — `secondary` "
-                                 "holds the same frame into four alternating output sets (DESIGN.md §5)"},
+                         "note": "achieved = 44 B x pixels / (classify + render kernel time per frame, HIP events on the launch stream). "
+                                 "N = 1: frac is measured on a pass of the same frames into FOUR alternating output sets (no Infinity-Cache "
+                                 "reuse between frames: what HBM served); frac_cached is the timed loop of `value`, one output set as in the "
+                                 "reference (REFL/hello_vulkan.h:123). What binds: the HBM fraction exceeds the FP32-VALU fraction by an order "
+                                 "of magnitude; the frame is a mixture — ~85 % of the pixels are constant fills at the chip's store ceiling "
+                                 "(~6.2 TB/s), the rest is latency-bound root finding (`solved_tests_per_s`, `flops`)"},
         }
         if world == 1 and not a.no_secondary:
             try:

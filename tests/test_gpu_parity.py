@@ -530,11 +530,82 @@ def test_rccl_collective_path_world_1(tr):
             assert torch.equal(full.view(torch.int32), want.view(torch.int32))
             assert torch.equal(last3[1].view(torch.int32), want.view(torch.int32))
             assert not torch.equal(last3[0].view(torch.int32), want.view(torch.int32))
+            # the same three streams with a whole STEP captured into one hipGraph (what bench.py --gpus N replays): 6 frames
+            # over 3 streams and 6 output sets per replay, the gather of the step's last frame issued eagerly behind it;
+            # two replays, an eager frame loop in between, then the tiled part of an 8-rank job the same way (no gather)
+            pc3 = camera.baseline_push(3)
+            frame = trtd.TiledFrame([tr] + extra, W, H, 1, 0, dev, gather="fp32", force_collective=True, gather_every=6,
+                                    want_hits=("t",), output_sets=6)
+            assert frame.n_sets == 6
+            for _ in range(6):
+                frame.render(sc, g, pc3, abi.TRT_CAMERA_PINHOLE, stream)
+            frame.restart()
+            for buf in frame.locals:
+                buf.fill_(-7.0)
+            frame.capture_step(sc, g, pc3, abi.TRT_CAMERA_PINHOLE, stream, 6)
+            frame.step(stream)
+            frame.step(stream)
+            full = frame.finish()
+            torch.cuda.synchronize()
+            assert torch.equal(full.view(torch.int32), want.view(torch.int32))
+            for buf in frame.locals:
+                assert torch.equal(buf.view(torch.int32), want.view(torch.int32))
+            with pytest.raises(ValueError):
+                frame.capture_step(sc, g, pc3, abi.TRT_CAMERA_PINHOLE, stream, 4)   # not whole rounds of the six output sets
+            til = trtd.TiledFrame([tr] + extra, W, H, 8, 3, dev, gather="none", group_rows=8)
+            for _ in range(3):
+                til.render(sc, g, pc3, abi.TRT_CAMERA_PINHOLE, stream)
+            til.restart()
+            eager = [b.clone() for b in til.locals]
+            for b in til.locals:
+                b.zero_()
+            til.capture_step(sc, g, pc3, abi.TRT_CAMERA_PINHOLE, stream, 9)
+            til.step(stream)
+            til.finish()
+            torch.cuda.synchronize()
+            rows = torch.tensor(trtd.owned_rows(H, 8, 8, 3), device=dev)
+            for b, e in zip(til.locals, eager):
+                assert torch.equal(b.view(torch.int32), e.view(torch.int32)) and torch.equal(b.view(torch.int32), want[rows].view(torch.int32))
         finally:
             for t in extra:
                 t.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_line_has_what_the_driver_parses():
+    """`python bench.py` as the driver runs it (N = 1, small K, no CPU baseline / secondary passes to keep it short): ONE
+    JSON line with the contract's keys, `roofline` priced on the pass into four alternating output sets with the
+    single-image figure beside it, and — with the CPU baseline enabled on a small frame — a `cpu_baseline` object."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(*extra):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--frames-per-step", "2", *extra],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, p.stdout[-2000:]
+        return json.loads(lines[0])
+
+    j = run("--no-cpu-baseline", "--no-secondary")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 1 and j["value"] > 2.0e9 and j["vs_baseline"] is None
+    assert "BASELINE config 3" in j["config"]["workload"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
+    assert r["output_sets"] == 4 and r["frac_cached"] is not None and r["kernel_ms_cached"] > 0
+    assert abs(r["achieved"] - 44 * 4096 * 4096 / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert "cpu_baseline" not in j
+    # CPU baseline leg on a frame small enough for a test (the oracle renders whole frames of the workload)
+    j = run("--no-secondary", "--size", "512")
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == j["unit"]
 
 
 def test_trace_dev_full_size_matches_render(tr):

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Does overlapping consecutive frames on K streams (one trt_ctx + one output set per stream) lift the latency floor of a
-1/N part?  usage: bench_tiled_streams.py [--parts 8] [--part 0] [--streams 1 2 3 4] [--scene nested] [--f64]"""
+"""What one rank of an N-GPU job spends per frame on its 1/N part, with K frames in flight on K streams (one trt_ctx +
+one output set per stream) — launched eagerly through Python + the C ABI, and replayed as ONE hipGraph per batch
+(--graph: TiledFrame.capture_step, what bench.py --gpus N does), so that the host's share of a frame can be told from
+the GPU's.  Wall clock per frame over batches of --frames frames; run it under `rocprofv3 --kernel-trace` and feed the
+trace to tools/tiled_trace_report.py for the GPU-side figures (kernel durations, gaps, span per frame).
+usage: bench_tiled_streams.py [--parts 8] [--part 0] [--streams 1 2 3 4] [--graph] [--both] [--scene nested] [--f64]"""
 import argparse, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,6 +17,10 @@ ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--parts", type=int, default=8)
 ap.add_argument("--part", type=int, default=0)
 ap.add_argument("--streams", type=int, nargs="+", default=[1, 2, 3, 4])
+ap.add_argument("--frames", type=int, default=192, help="frames per batch (a multiple of every --streams value)")
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--graph", action="store_true", help="replay each batch as one hipGraph")
+ap.add_argument("--both", action="store_true", help="eager and graph, interleaved rounds in one process")
 ap.add_argument("--scene", default="single", choices=["single", "nested"], help="nested: the eight nested tori of config 4")
 ap.add_argument("--f64", action="store_true", help="FP64 solve (config 4)")
 a = ap.parse_args()
@@ -21,36 +29,46 @@ W = H = a.size
 sc = camera.single_torus_scene() if a.scene == "single" else camera.nested_tori_scene()
 g, pc = camera.baseline_camera(W, H), camera.baseline_push(5)
 n = a.parts
-G = trtd.default_group_rows(H, n, trtd.DEFAULT_CYCLES) if n > 1 else H
-t = abi.trt_tiling(G, n, a.part, 1 if n > 1 else 0)
+G = trtd.default_group_rows(H, n, trtd.DEFAULT_CYCLES) if n > 1 else None
+cur = torch.cuda.current_stream()
 for K in a.streams:
+    F = a.frames - a.frames % K
     trs = [Tracer(0) for _ in range(K)]
     if a.f64:
         for tr_ in trs:
             tr_.set_solver(abi.TRT_SOLVE_F64)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
-    rows = trs[0].tiling_rows(t, H) if n > 1 else H
-    bufs = [(torch.empty(rows, W, 4, device=dev), {k: torch.empty(rows * W, device=dev) for k in ("t", "px", "py", "pz", "nx", "ny", "nz")}) for _ in range(K)]
-    ptrs = [(r.data_ptr(), {k: v.data_ptr() for k, v in h.items()}) for r, h in bufs]
+    frame = trtd.TiledFrame(trs, W, H, n, a.part, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz"), gather="none", group_rows=G)
+    for _ in range(2 * K):
+        frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, cur)
+    frame.restart()
+    modes = ["eager", "graph"] if a.both else (["graph"] if a.graph else ["eager"])
+    if "graph" in modes:
+        frame.capture_step(sc, g, pc, abi.TRT_CAMERA_PINHOLE, cur, F)
 
-    def frame(i):
-        k = i % K
-        if n > 1:
-            trs[k].render_tiled_dev(sc, g, pc, W, H, t, ptrs[k][0], hit_ptrs=ptrs[k][1], stream=streams[k].cuda_stream)
+    def batch(mode):
+        if mode == "graph":
+            frame.step(cur)
         else:
-            trs[k].render_dev(sc, g, pc, W, H, ptrs[k][0], hit_ptrs=ptrs[k][1], stream=streams[k].cuda_stream)
-    for i in range(16):
-        frame(i)
+            for _ in range(F):
+                frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, cur)
+            frame.join(cur)
+
+    out = {m: [] for m in modes}
+    for m in modes:
+        batch(m)
     torch.cuda.synchronize()
-    out = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(256):
-            frame(i)
-        torch.cuda.synchronize()
-        out.append((time.perf_counter() - t0) / 256)
-    ms = statistics.median(out) * 1e3
-    print(f"{a.scene}{' f64' if a.f64 else ''}: {n} parts, part {a.part}, {K} stream(s): {ms * 1e3:.1f} us per frame (wall, 256 frames)", flush=True)
+    for _ in range(a.rounds):
+        for m in modes:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch(m)
+            torch.cuda.synchronize()
+            out[m].append((time.perf_counter() - t0) / F)
+    for m in modes:
+        us = statistics.median(out[m]) * 1e6
+        print(f"{a.scene}{' f64' if a.f64 else ''}: {n} parts, part {a.part}, {K} stream(s), {m}: {us:.1f} us per frame "
+              f"(wall, batches of {F} frames, median of {a.rounds}; min {min(out[m]) * 1e6:.1f})", flush=True)
+    frame.finish()
+    del frame
     for tr in trs:
         tr.close()

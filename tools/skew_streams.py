@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do the eight output streams of a frame (rgba + t,P,N: 2^28 and 7 x 2^26 bytes at 4096^2) alias in the memory system when
 they sit at power-of-two distances?  Times the config-3 frame with the first-hit streams carved out of one allocation at
-base + k*(size + skew) for several skews.  usage: skew_test.py [size]"""
+base + k*(size + skew) for several skews.  usage: skew_streams.py [size]"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _tuning  # noqa: E402

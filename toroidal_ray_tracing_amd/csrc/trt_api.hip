@@ -63,6 +63,18 @@ struct trt_ctx {
   DevBuf d_bins;   // … binned form: per-bin count / offset / cursor words (count zero between calls)
   DevBuf d_recs;   // … binned form: point records sorted by bin
   std::vector<void*> retired;   // scratch blocks replaced by larger ones: a hipGraph captured earlier may still use them
+  bool               bins_dirty = false;   // a re-projection failed between its count and its resolve: zero d_bins before the next one
+
+  // The scene the caller passed last, validated and turned into kernel constants: a frame loop passes the same few
+  // hundred bytes every frame, and a 1/8-part frame is short enough for the host's share of a launch to show.
+  struct SceneCache {
+    bool         valid = false;
+    int          precision = -1;
+    uint32_t     n_tori = 0, n_mat = 0;
+    trt_torus    tori[TRT_MAX_TORI];
+    trt_material mat[TRT_MAX_MATERIALS];
+    SceneK       K;
+  } scene_cache;
 };
 
 namespace {
@@ -100,17 +112,29 @@ bool capturing(hipStream_t st)
 
 constexpr size_t kSplatBinWordsAlloc = 8192;   // = kSplatMaxBins of trt_kernels.hip
 
-// Grow-only scratch.  A block that is replaced by a larger one is RETIRED, not freed, until trt_destroy: a hipGraph
-// captured earlier keeps replaying on the old block (its kernel arguments hold the old address and capacity), and
-// work still in flight on another stream may be using it.  hipMalloc is illegal while `st` is being captured — then
-// the call is refused instead (include/trt.h: size the ctx with an eager call first).
-int grow(trt_ctx* ctx, DevBuf& b, size_t bytes, hipStream_t st = nullptr)
+// Grow-only scratch.  Scratch that a *_dev entry point hands to a kernel (tile lists, cost words, toroidal tables,
+// re-projection keys / bins / records: `graph_visible`) is RETIRED when a larger block replaces it, not freed, until
+// trt_destroy: a hipGraph captured earlier keeps replaying on the old block (its kernel arguments hold the old address
+// and capacity), and work still in flight on another stream may be using it; such blocks grow by at least half, so that
+// a ctx driven through increasing sizes retains at most ≈3× its peak.  The staging buffers of the host-pointer entry
+// points (which synchronise before they return and cannot be captured) are freed at once.  hipMalloc is illegal while
+// `st` is being captured — then the call is refused instead (include/trt.h: size the ctx with an eager call first).
+int grow(trt_ctx* ctx, DevBuf& b, size_t bytes, hipStream_t st = nullptr, bool graph_visible = true)
 {
   if(bytes <= b.cap) return TRT_OK;
   if(capturing(st))
     return fail(ctx, TRT_E_INVALID, "the ctx's scratch would have to grow (%zu -> %zu bytes) while the stream is being "
                 "captured into a hipGraph: make one eager call with the same sizes first", b.cap, bytes);
-  if(b.p) ctx->retired.push_back(b.p);
+  if(b.p)
+  {
+    if(graph_visible)
+    {
+      ctx->retired.push_back(b.p);
+      if(bytes < b.cap + b.cap / 2) bytes = b.cap + b.cap / 2;
+    }
+    else
+      TRT_HIP(ctx, hipFree(b.p));   // (synchronises with the device: nothing is using the block any more)
+  }
   b.p = nullptr;
   b.cap = 0;
   TRT_HIP(ctx, hipMalloc(&b.p, bytes));
@@ -135,7 +159,11 @@ void torus_prepare(const trt_torus& t, TorusK<Real>& k)
   k.fourR2 = (Real)4 * R2;
 }
 
-int build_scene(trt_ctx* ctx, const trt_scene* s, SceneK& out)
+int build_scene_uncached(trt_ctx* ctx, const trt_scene* s, SceneK& out);
+
+// The validated kernel constants of `s` — from the ctx's cache when the caller passes the scene of the previous call
+// again (compared byte for byte, solver included), else built and cached.
+int build_scene(trt_ctx* ctx, const trt_scene* s, const SceneK*& out)
 {
   if(!s || !s->tori || !s->materials)
     return fail(ctx, TRT_E_INVALID, "scene: NULL scene / tori / materials");
@@ -144,6 +172,26 @@ int build_scene(trt_ctx* ctx, const trt_scene* s, SceneK& out)
   if(s->n_materials < 1 || s->n_materials > TRT_MAX_MATERIALS)
     return fail(ctx, TRT_E_SCENE, "scene: n_materials=%u outside 1..%d", s->n_materials,
                 TRT_MAX_MATERIALS);
+  auto& c = ctx->scene_cache;
+  if(!(c.valid && c.precision == ctx->precision && c.n_tori == s->n_tori && c.n_mat == s->n_materials
+       && !std::memcmp(c.tori, s->tori, s->n_tori * sizeof(trt_torus))
+       && !std::memcmp(c.mat, s->materials, s->n_materials * sizeof(trt_material))))
+  {
+    c.valid = false;
+    if(int rc = build_scene_uncached(ctx, s, c.K)) return rc;
+    c.precision = ctx->precision;
+    c.n_tori = s->n_tori;
+    c.n_mat  = s->n_materials;
+    std::memcpy(c.tori, s->tori, s->n_tori * sizeof(trt_torus));
+    std::memcpy(c.mat, s->materials, s->n_materials * sizeof(trt_material));
+    c.valid = true;
+  }
+  out = &c.K;
+  return TRT_OK;
+}
+
+int build_scene_uncached(trt_ctx* ctx, const trt_scene* s, SceneK& out)
+{
   std::memset(&out, 0, sizeof out);
   out.n_tori = (int)s->n_tori;
   out.n_mat  = (int)s->n_materials;
@@ -429,8 +477,9 @@ extern "C" int trt_trace_dev(trt_ctx* ctx, const trt_rays* in, const trt_scene* 
   if(!in || !out) return fail(ctx, TRT_E_INVALID, "trt_trace: NULL rays or hits");
   if(in->n && (!in->ox || !in->oy || !in->oz || !in->dx || !in->dy || !in->dz))
     return fail(ctx, TRT_E_INVALID, "trt_trace: NULL ray stream");
-  SceneK S;
-  if(int rc = build_scene(ctx, scene, S)) return rc;
+  const SceneK* Sp = nullptr;
+  if(int rc = build_scene(ctx, scene, Sp)) return rc;
+  const SceneK& S = *Sp;
   TRT_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   TraceArgs   a;
@@ -470,7 +519,7 @@ extern "C" int trt_trace(trt_ctx* ctx, const trt_rays* in, const trt_scene* scen
   const float** dptr_in[6] = {&din.ox, &din.oy, &din.oz, &din.dx, &din.dy, &din.dz};
   for(int k = 0; k < 6 && in->n; ++k)
   {
-    if(int rc = grow(ctx, ctx->d_in[k], bytes)) return rc;
+    if(int rc = grow(ctx, ctx->d_in[k], bytes, nullptr, false)) return rc;
     TRT_HIP(ctx, hipMemcpyAsync(ctx->d_in[k].p, src[k], bytes, hipMemcpyHostToDevice, nullptr));
     *dptr_in[k] = (const float*)ctx->d_in[k].p;
   }
@@ -481,7 +530,7 @@ extern "C" int trt_trace(trt_ctx* ctx, const trt_rays* in, const trt_scene* scen
     *dptr_out[k] = nullptr;
     if(dst[k] && in->n)
     {
-      if(int rc = grow(ctx, ctx->d_out[k], bytes)) return rc;
+      if(int rc = grow(ctx, ctx->d_out[k], bytes, nullptr, false)) return rc;
       *dptr_out[k] = ctx->d_out[k].p;
     }
   }
@@ -532,8 +581,9 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
   if(tiling && (tiling->group_rows == 0 || tiling->n_parts == 0 || tiling->part >= tiling->n_parts))
     return fail(ctx, TRT_E_INVALID, "trt_render_tiled: bad tiling group_rows=%u n_parts=%u part=%u",
                 tiling->group_rows, tiling->n_parts, tiling->part);
-  SceneK S;
-  if(int rc = build_scene(ctx, scene, S)) return rc;
+  const SceneK* Sp = nullptr;
+  if(int rc = build_scene(ctx, scene, Sp)) return rc;
+  const SceneK& S = *Sp;
   TRT_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   RenderArgs  a;
@@ -675,7 +725,7 @@ extern "C" int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc
   float*       d_rgba = nullptr;
   if(rgba_out)
   {
-    if(int rc = grow(ctx, ctx->d_rgba, npx * 16)) return rc;
+    if(int rc = grow(ctx, ctx->d_rgba, npx * 16, nullptr, false)) return rc;
     d_rgba = (float*)ctx->d_rgba.p;
   }
   trt_hits dh;
@@ -690,7 +740,7 @@ extern "C" int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc
     for(int k = 0; k < 8; ++k)
       if((dst[k] = h[k]))
       {
-        if(int rc = grow(ctx, ctx->d_out[k], npx * 4)) return rc;
+        if(int rc = grow(ctx, ctx->d_out[k], npx * 4, nullptr, false)) return rc;
         *dptr[k] = ctx->d_out[k].p;
       }
   }

@@ -88,14 +88,17 @@ class TiledFrame:
     """
 
     def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=None,
-                 gather=True, force_collective=False, gather_every=1):
+                 gather=True, force_collective=False, gather_every=1, output_sets=1):
         """tracer: one Tracer, or a list of K of them (K render streams, one context each).
         gather: True / "fp32" — all-gather the rgba32f framebuffer (default, what north_star
         prescribes); "rgba8" — tonemap each rank's rows (trt_post_dev, post.frag) and all-gather
         the 8-bit image a swapchain would present: 4x fewer bytes over xGMI, the rgba32f image
         stays sharded; False / "none" — no collective.  force_collective: issue the collective
         even when world == 1 (exercises the RCCL path on a one-GPU box).  gather_every: F > 1 gathers only every F-th
-        frame (frames F-1, 2F-1, …)."""
+        frame (frames F-1, 2F-1, …).  output_sets: M > K rotates the frames over M output sets (rounded up to a multiple
+        of the K streams, so that a set always belongs to one stream) — consecutive frames then never write the same
+        buffers and nothing of a frame is still in the 256-MB Infinity Cache when it is written again (bench.py's
+        roofline pass)."""
         self.trs = list(tracer) if isinstance(tracer, (list, tuple)) else [tracer]
         self.tr = self.trs[0]
         self.W, self.H, self.world, self.rank = W, H, world, rank
@@ -118,10 +121,11 @@ class TiledFrame:
         self.device = torch.device(device)
         K = len(self.trs)
         f32 = dict(dtype=torch.float32, device=device)
-        # one output set per render stream
-        self.locals = [torch.empty(self.local_rows, W, 4, **f32) for _ in range(K)]
+        # one output set per render stream, or more (output_sets): frame i renders on stream i % K into set i % n_sets
+        self.n_sets = ((max(K, int(output_sets)) + K - 1) // K) * K
+        self.locals = [torch.empty(self.local_rows, W, 4, **f32) for _ in range(self.n_sets)]
         self.hit_sets = []
-        for _ in range(K):
+        for _ in range(self.n_sets):
             h = {k: torch.empty(self.local_pixels, **f32) for k in want_hits if k != "id"}
             if "id" in want_hits:
                 h["id"] = torch.empty(self.local_pixels, dtype=torch.int32, device=device)
@@ -139,7 +143,8 @@ class TiledFrame:
         self._pending = [[], []]   # in-flight all-gathers reading staging buffer j
         self._stage = 0            # staging buffer of the next gather
         self._k = 0                # frames rendered
-        self._last = 0             # gathered frame (or, without a gather, output set) handed out by `full`
+        self._last = 0             # gathered frame (or, without a gather, output set) that finish() hands out
+        self._newest = None        # gathered frame of the most recent gather (in flight until finish())
 
     @property
     def local(self):
@@ -147,7 +152,9 @@ class TiledFrame:
 
     @property
     def full(self):
-        """The most recent complete frame: the last GATHERED one (without a gather: the last one rendered)."""
+        """The frame finish() returned last: the last GATHERED one (without a gather: the last one rendered).  Valid only
+        between finish() and the next render(): while frames are in flight both gathered frames may be the target of
+        a collective that has not been waited for."""
         return self.fulls[self._last]
 
     def describe(self):
@@ -166,20 +173,22 @@ class TiledFrame:
         return torch.cuda.stream(stream) if self.device.type == "cuda" else contextlib.nullcontext()
 
     def _retire(self, j):
-        """Order the current stream behind the gathers that read staging buffer j: gathered frame j is then complete."""
+        """Order the current stream behind the gathers that read staging buffer j (and wrote gathered frame j)."""
         if self._pending[j]:
             for w in self._pending[j]:
                 w.wait()
             self._pending[j] = []
-            self._last = j
 
     def render(self, scene, g, pc, camera, stream, events=None):
         """One frame: render this rank's rows on the frame's stream (the caller's `stream`, or with K tracers the next of
         the K own streams, which branch off `stream` at the first frame after construction / join()); on a gather frame
         copy or tonemap the rows into a staging buffer and start the all-gathers behind that.
-        `events` = (start, end) torch.cuda.Events recorded around the render launches only."""
+        `events` = (start, end) torch.cuda.Events recorded around the render launches only.
+        Returns nothing: a frame is handed out by finish() (with frames and collectives in flight neither gathered
+        frame is stable)."""
         K = len(self.trs)
         k = self._k % K
+        o = self._k % self.n_sets   # output set; n_sets is a multiple of K, so set o is only ever written on stream k
         self._k += 1
         self._caller = stream
         if self._own is not None:
@@ -191,34 +200,91 @@ class TiledFrame:
             s = self._own[k]
         else:
             s = stream
-        tr, hp = self.trs[k], {n: v.data_ptr() for n, v in self.hit_sets[k].items()}
+        tr, hp = self.trs[k], {n: v.data_ptr() for n, v in self.hit_sets[o].items()}
         do_gather = self.gather and self._k % self.gather_every == 0
         if events:
             events[0].record(s)
         if self.world == 1:
-            tr.render_dev(scene, g, pc, self.W, self.H, self.locals[k].data_ptr(), camera=camera, hit_ptrs=hp, stream=s.cuda_stream)
+            tr.render_dev(scene, g, pc, self.W, self.H, self.locals[o].data_ptr(), camera=camera, hit_ptrs=hp, stream=s.cuda_stream)
         else:
-            tr.render_tiled_dev(scene, g, pc, self.W, self.H, self.tiling, self.locals[k].data_ptr(), camera=camera,
+            tr.render_tiled_dev(scene, g, pc, self.W, self.H, self.tiling, self.locals[o].data_ptr(), camera=camera,
                                 hit_ptrs=hp, stream=s.cuda_stream)
         if events:
             events[1].record(s)
         if do_gather:
-            j = self._stage
-            self._stage ^= 1
-            with self._on(s):
-                self._retire(j)   # the gather that read this staging buffer two gathers ago is complete before it is overwritten
-                if self.mode == "rgba8":
-                    tr.post_dev(self.locals[k].data_ptr(), self.local_pixels, 0, self.sends[j].data_ptr(), stream=s.cuda_stream)
-                else:
-                    self.sends[j].copy_(self.locals[k], non_blocking=True)
-                G, span = self.group_rows if self.world > 1 else self.H, (self.group_rows * self.world if self.world > 1 else self.H)
-                for c in range(self.cycles):
-                    self._pending[j].append(dist.all_gather_into_tensor(
-                        self.fulls[j][c * span:(c + 1) * span], self.sends[j][c * G:(c + 1) * G], async_op=True))
-            return self.fulls[j]
+            self._gather(o, s, tr)
         if not self.gather:
-            self._last = k
-        return self.fulls[self._last]
+            self._last = o
+
+    def _gather(self, o, s, tr):
+        """Copy or tonemap output set o into a staging buffer on stream s and start the all-gathers behind that."""
+        j = self._stage
+        self._stage ^= 1
+        with self._on(s):
+            self._retire(j)   # the gather that read this staging buffer two gathers ago is complete before it is overwritten
+            if self.mode == "rgba8":
+                tr.post_dev(self.locals[o].data_ptr(), self.local_pixels, 0, self.sends[j].data_ptr(), stream=s.cuda_stream)
+            else:
+                self.sends[j].copy_(self.locals[o], non_blocking=True)
+            G, span = self.group_rows if self.world > 1 else self.H, (self.group_rows * self.world if self.world > 1 else self.H)
+            for c in range(self.cycles):
+                self._pending[j].append(dist.all_gather_into_tensor(
+                    self.fulls[j][c * span:(c + 1) * span], self.sends[j][c * G:(c + 1) * G], async_op=True))
+        self._newest = j
+
+    # -- a whole step as ONE hipGraph ------------------------------------------------------------------------------
+    def capture_step(self, scene, g, pc, camera, stream, n_frames):
+        """Capture `n_frames` consecutive frames — K streams, their fork and join, two kernel nodes per frame — into one
+        hipGraph; step() then replays it with ONE host call instead of 2·n_frames launches through Python and the C ABI
+        (a 1/8 part of the baseline frame takes the GPU ≈15 µs; enqueueing it eagerly takes the host as long).  The
+        *_dev entry points are capturable once the contexts' scratch is sized (include/trt.h): render one eager frame
+        per stream first.  The frames of a step must map to streams and output sets the same way in every step:
+        n_frames must be a multiple of the number of output sets and the frame counter must stand at a multiple of it
+        (restart()).  A gather (every gather_every-th frame) stays outside the graph: step() issues it eagerly behind
+        the replay, and it may only fall on a step's last frame."""
+        if self.device.type != "cuda":
+            raise RuntimeError("capture_step needs a GPU")
+        if n_frames % self.n_sets or self._k % self.n_sets:
+            raise ValueError(f"a captured step must cover whole rounds of the {self.n_sets} output sets (n_frames={n_frames}, frame counter {self._k})")
+        if self.gather and self.gather_every % n_frames:
+            raise ValueError("a gather may only fall on the last frame of a captured step (gather_every must be a multiple of n_frames)")
+        self.join(stream)
+        K = len(self.trs)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(stream)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
+            if self._own is not None:
+                for s in self._own:
+                    s.wait_stream(side)
+            for f in range(n_frames):
+                k, o = f % K, f % self.n_sets
+                s = self._own[k] if self._own is not None else side
+                hp = {n: v.data_ptr() for n, v in self.hit_sets[o].items()}
+                if self.world == 1:
+                    self.trs[k].render_dev(scene, g, pc, self.W, self.H, self.locals[o].data_ptr(), camera=camera, hit_ptrs=hp, stream=s.cuda_stream)
+                else:
+                    self.trs[k].render_tiled_dev(scene, g, pc, self.W, self.H, self.tiling, self.locals[o].data_ptr(), camera=camera,
+                                                 hit_ptrs=hp, stream=s.cuda_stream)
+            if self._own is not None:
+                for s in self._own:
+                    side.wait_stream(s)
+        stream.wait_stream(side)
+        self._graph, self._graph_frames = graph, n_frames
+        return graph
+
+    def step(self, stream):
+        """Replay the captured step on `stream` (which must be torch's current stream); on a gather step, start the
+        gather of the step's last frame behind it."""
+        n = self._graph_frames
+        self._caller = stream
+        self._graph.replay()
+        self._k += n
+        o = (self._k - 1) % self.n_sets
+        if self.gather and self._k % self.gather_every == 0:
+            self._gather(o, stream, self.trs[(n - 1) % len(self.trs)])
+        if not self.gather:
+            self._last = o
 
     def join(self, stream=None):
         """K own streams: order `stream` (default: the stream of the last render call) behind every frame issued so far;
@@ -242,5 +308,7 @@ class TiledFrame:
         if self.gather:
             with self._on(self._caller) if self._caller is not None else self._on(None):
                 for i in range(2):
-                    self._retire(self._stage ^ i)   # oldest gather first: the newest one sets `full`
+                    self._retire(self._stage ^ i)   # oldest gather first
+            if self._newest is not None:
+                self._last = self._newest           # every gather has been waited for: the newest frame is complete
         return self.full
