@@ -35,7 +35,8 @@ The same line carries the OTHER cadence too, measured in the same job right afte
 reference's loop does when it presents each frame, REFL/main.cpp:298-313; link-bound) — the
 figure that is like-for-like with round 1's N > 1 line.  `gather_ms` and `render_only_primary_tests_per_s`
 say what a gather and the sharded renders cost on their own.  A rank's step of F frames × K streams is
-captured once into a hipGraph and replayed (`--no-graph`: eager launches).
+rendered N frames per launch (`--batch`, trt_render_batch_dev: N parts of 1/N frame are the work of one full
+frame and fill the chip like one); `--graph` replays each step as one captured hipGraph (no gain: GPU-bound).
 
 Roofline (N = 1): the timed loop writes every frame into the same buffers — the reference's situation, one
 offscreen image — and part of what a frame leaves in the 256-MB Infinity Cache is overwritten there by the
@@ -46,7 +47,7 @@ HIP events like the first; the single-image figure stays beside it as `roofline.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-step F]
                        [--variant listed|persistent|static] [--gather fp32|rgba8|none] [--gather-every step|K]
-                       [--no-cpu-baseline] [--no-secondary] [--size 4096] [--depth 5] [--output-sets M] [--no-graph]
+                       [--no-cpu-baseline] [--no-secondary] [--size 4096] [--depth 5] [--output-sets M] [--batch B] [--graph]
 """
 import argparse
 import ctypes as C
@@ -93,7 +94,7 @@ def parse():
                     help="N>1: what is all-gathered (default: the rgba32f framebuffer)")
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight per rank, each on its own HIP stream with its own context and output set "
-                         "(default: 1 for N = 1, 4 for N > 1 — a 1/N part of the frame does not fill the chip on one stream)")
+                         "(default 1; round 2 used 4 for N > 1 — superseded by --batch, with which it cannot be combined)")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="one GPU: run the N>1 code path (RCCL group of one rank, forced collectives) — a rehearsal, not a measurement")
     ap.add_argument("--gather-every", default="step",
@@ -109,8 +110,12 @@ def parse():
     ap.add_argument("--output-sets", type=int, default=1,
                     help="output sets the timed loop rotates over (default 1: one offscreen image, like the reference; 4: no "
                          "Infinity-Cache reuse between frames — the roofline pass always uses 4)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="N>1: launch every frame eagerly instead of replaying the step's hipGraph")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per launch (trt_render_batch_dev).  Default: N for N > 1 — N parts of 1/N frame are the work of one "
+                         "full frame and fill the chip like one — and 1 for N = 1")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay every step as one captured hipGraph instead of launching it eagerly (measured: no gain — the "
+                         "frames are bound by the GPU, not by the host's launches; DESIGN.md §7)")
     ap.add_argument("--no-other-cadence", action="store_true",
                     help="N>1: skip the second measurement (a gather after EVERY frame, rgba8 and fp32)")
     return ap.parse_args()
@@ -173,8 +178,9 @@ def cpu_baseline(sc, g, pc, W, H):
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except Exception:
         pass
-    rgba = np.zeros((H, W, 4), np.float32)
-    hits = abi.alloc_hits(W * H)
+    npx = max(W * H, 2048 * 2048)   # configs 1 and 2 below render into the same buffers
+    rgba = np.zeros(npx * 4, np.float32)
+    hits = abi.alloc_hits(npx)
     for v in hits.values():
         v[...] = 0
     hs = abi.hits_struct({k: hits[k] for k in ("t", "px", "py", "pz", "nx", "ny", "nz")})
@@ -375,6 +381,10 @@ class _PatternTracer:
         buf[..., 2] = np.arange(W, dtype=np.float32)[None, :]
         buf[..., 3] = 1.0
 
+    def render_batch_dev(self, scene, frames, W, H, tiling=None, camera=0, stream=0):
+        for g, pc, rgba_ptr, hit_ptrs in frames:
+            self.render_tiled_dev(scene, g, pc, W, H, tiling, rgba_ptr, camera=camera, hit_ptrs=hit_ptrs, stream=stream)
+
     render_dev = None
 
 
@@ -389,8 +399,10 @@ def dry_run(a, world, rank):
     class _S:
         cuda_stream = 0
     ge = 2 if a.gather_every == "step" else max(1, int(a.gather_every))   # rehearsal: a "step" of two frames
+    from toroidal_ray_tracing_amd import abi
+    nb = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 else 1)   # as worker(): N frames per launch
     frame = trtd.TiledFrame(_PatternTracer(rank), W, H, world, rank, torch.device("cpu"), group_rows=a.group_rows or None,
-                            gather=a.gather if a.gather != "rgba8" else "fp32", gather_every=ge)
+                            gather=a.gather if a.gather != "rgba8" else "fp32", gather_every=ge, batch=nb)
     ok = True
     if world > 1:
         for _ in range(2 * ge + 1):
@@ -450,10 +462,11 @@ def worker(a, world, rank, local):
         (0.0, 1.5, -4.0), tuple(float(v) for v in a.center.split(",")), W, H)
     pc = camera.baseline_push(a.depth)
     gather_every = F if a.gather_every == "step" else max(1, int(a.gather_every))
-    # frames in flight: 4 streams for the 1/N parts of N > 1 (one does not fill the chip), ONE for the full frame — and one
-    # when every frame is gathered: the render is then timed with an event pair per frame, which concurrent frames on
-    # other streams would stretch (each pair would include the contention of up to K frames)
-    n_streams = a.streams if a.streams > 0 else (4 if world > 1 and gather_every != 1 else 1)
+    # A 1/N part of the frame does not fill the chip: N > 1 renders N consecutive frames' parts per launch (a batch: the work
+    # of one full frame), on ONE stream.  (Round 2 kept 4 frames in flight on 4 streams instead — `--streams 4 --batch 1`:
+    # 17-25 µs per 1/8 part depending on how the runtime maps the streams to hardware queues, against 14-15 µs batched.)
+    n_streams = a.streams if a.streams > 0 else 1
+    n_batch = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 and n_streams == 1 else 1)
     trs = [Tracer(local) for _ in range(n_streams)]
     tr = trs[0]
     if a.variant:
@@ -496,7 +509,7 @@ def worker(a, world, rank, local):
         # HIP events on the launch stream (torch's current stream IS the stream handed to trt_render*_dev, and the stream a
         # graph is replayed on).  One pair around each step's F frames; with a gather after EVERY frame a pair around every
         # frame's render launches instead, because the stream then also carries the waits on the gathers.
-        per_frame = multi and frame.gather and frame.gather_every == 1 and not graphed
+        per_frame = multi and frame.gather and frame.gather_every == 1 and not graphed and frame.batch == 1
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(steps * (F if per_frame else 1))]
         sync_all()
@@ -521,7 +534,7 @@ def worker(a, world, rank, local):
         return float(tmax.item()), sum(e0.elapsed_time(e1) for e0, e1 in evs) / (steps * F), graphed
 
     frame = trtd.TiledFrame(trs, W, H, world, rank, dev, want_hits=want_hits, gather=a.gather, group_rows=a.group_rows or None,
-                            gather_every=gather_every, force_collective=a.rehearse_collective, output_sets=a.output_sets)
+                            gather_every=gather_every, force_collective=a.rehearse_collective, output_sets=a.output_sets, batch=n_batch)
 
     # one counted pass (untimed): how many ray–torus tests one frame executes
     tr.enable_stats(True)
@@ -537,8 +550,7 @@ def worker(a, world, rank, local):
     cnt = dict(zip(keys, (int(v) for v in tests.tolist())))
     assert cnt["pixels"] == W * H and cnt["primary_tests"] == W * H * sc.n_tori, cnt
 
-    # the step of a 1/N part is captured into a hipGraph (launch-bound otherwise); the full frame of N = 1 is not
-    use_graph = multi and not a.no_graph and (gather_every % F == 0 or not frame.gather) and F % frame.n_sets == 0
+    use_graph = a.graph and (gather_every % F == 0 or not frame.gather) and F % frame.n_sets == 0
     dt, kern_ms, graphed = measure(frame, a.steps, a.warmup, use_graph)
     n_frames = a.steps * F
 
@@ -577,7 +589,7 @@ def worker(a, world, rank, local):
         for mode in ("rgba8", "fp32"):
             try:
                 fr = trtd.TiledFrame(trs, W, H, world, rank, dev, want_hits=want_hits, gather=mode, group_rows=a.group_rows or None,
-                                     gather_every=1, force_collective=a.rehearse_collective)
+                                     gather_every=1, force_collective=a.rehearse_collective, batch=n_batch)
                 dto, _, _ = measure(fr, max(1, min(a.steps, 3)), 1, False)
                 other[mode] = {"value": max(1, min(a.steps, 3)) * F * cnt["primary_tests"] / dto, "unit": "primary ray-torus tests/s",
                                "ms_per_frame": dto / (max(1, min(a.steps, 3)) * F) * 1e3, "steps": max(1, min(a.steps, 3)),
@@ -661,6 +673,7 @@ def worker(a, world, rank, local):
             "step_launch": ("one hipGraph replay per step" if graphed else "eager launches"),
             "rehearse_collective": bool(a.rehearse_collective),
             "frames_in_flight": n_streams,
+            "frames_per_launch": n_batch,
             "output_sets": frame.n_sets,
             # the rank-local renders alone (max over ranks of the HIP-event render time per frame): the part of the path that shards
             "render_only_primary_tests_per_s": cnt["primary_tests"] / (kern_ms_max * 1e-3) if multi else None,

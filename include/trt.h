@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define TRT_VERSION_MAJOR 0
-#define TRT_VERSION_MINOR 2
+#define TRT_VERSION_MINOR 3
 
 /* ---- status codes ------------------------------------------------------------------ */
 enum {
@@ -48,6 +48,7 @@ enum {
 
 #define TRT_MAX_TORI      8 /* BASELINE config 4: "8 nested tori (tokamak shells)"       */
 #define TRT_MAX_MATERIALS 8
+#define TRT_MAX_BATCH     8 /* frames per trt_render_batch_dev call                        */
 
 /* ---- camera models ----------------------------------------------------------------- */
 enum {
@@ -224,6 +225,28 @@ int trt_render_tiled_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
                          uint32_t W, uint32_t H, const trt_tiling* tiling, int camera,
                          float* rgba_dev, trt_hits* first_hit_dev, trt_rendered_data* rendered_dev,
                          void* stream);
+
+/* A batch of consecutive frames of a frame loop in ONE pair of launches.  The reference records one command
+ * buffer per frame and keeps several of them in flight (REFL/main.cpp:249-257: prepareFrame / the swapchain's
+ * frames in flight); consecutive frames are independent of one another.  Here the frames of a batch share the
+ * scene, the image size, the tiling and the camera model; each has its own uniforms, push constants and output
+ * buffers (which must not overlap).  Why: a 1/8 part of a 4096² frame — what one rank of an 8-GPU job renders —
+ * does not fill an MI355X, and back-to-back small launches on one stream wait for each frame's slowest tile; eight
+ * such parts in one launch are the work of one full frame and run like one.  Results are those of
+ * n_frames calls of trt_render_tiled_dev / trt_render_dev, bit for bit.
+ * Restrictions (TRT_E_INVALID otherwise; render such frames one by one): the listed render variant and the default
+ * root solver (TRT_SOLVE_F32 / _F64); no RenderedData export; W <= 65528; 1 <= n_frames <= TRT_MAX_BATCH; with the
+ * toroidal camera all frames must share eye and centre (they may differ in rho: the rho sweep of
+ * BEF/main.cpp:236-258), because the ctx holds one set of trigonometry tables.  tiling may be NULL (whole frames). */
+typedef struct trt_frame {
+  const trt_globals* g;
+  const trt_push*    pc;
+  float*             rgba_dev;      /* rows of this part only when tiling->compact, else the full frame */
+  const trt_hits*    first_hit_dev; /* optional (NULL), device streams like trt_render_dev              */
+} trt_frame;
+
+int trt_render_batch_dev(trt_ctx* ctx, const trt_frame* frames, uint32_t n_frames, const trt_scene* scene,
+                         uint32_t W, uint32_t H, const trt_tiling* tiling, int camera, void* stream);
 
 /* ---- post pass: the tonemap of REFL/shaders/post.frag:33-37 ------------------------------ */
 /* out = pow(in, 1/2.2) on all four channels (GLSL pow(x,y) = exp2(y*log2(x)); x <= 0 or NaN -> 0).

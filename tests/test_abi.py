@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     L = lib.load()
     for name in _declared_functions():
         assert hasattr(L, name), name
-    assert L.trt_version() == 2   # TRT_VERSION_MAJOR*1000 + TRT_VERSION_MINOR
+    assert L.trt_version() == 3   # TRT_VERSION_MAJOR*1000 + TRT_VERSION_MINOR
 
 
 def test_release_library_reads_no_environment():

@@ -573,6 +573,108 @@ def test_rccl_collective_path_world_1(tr):
         dist.destroy_process_group()
 
 
+def test_render_batch_equals_single_frames(tr):
+    """trt_render_batch_dev — up to 8 frames of a frame loop in ONE pair of launches — against the same frames rendered one
+    by one: rgba, first-hit streams and the query counts bit for bit / equal.  Whole frames of a ragged size with a
+    camera that moves from frame to frame, the tiled part of a 4-rank job, eight nested tori with the FP64 solve (cost
+    feedback live: the batch is rendered twice), the toroidal camera with the per-tile classification and a rho sweep;
+    and what a batch refuses."""
+    import torch
+    from toroidal_ray_tracing_amd.tracer import TrtError
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    keys = ("t", "px", "py", "pz", "nx", "ny", "nz", "id")
+
+    def bufs(rows, W):
+        rgba = torch.full((rows, W, 4), -5.0, device=dev)
+        h = {k: torch.full((rows * W,), -5.0, device=dev) for k in keys[:-1]}
+        h["id"] = torch.full((rows * W,), -5, dtype=torch.int32, device=dev)
+        return rgba, h
+
+    def same(a, b):
+        return all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip([a[0]] + [a[1][k] for k in keys], [b[0]] + [b[1][k] for k in keys]))
+
+    def check(sc, frames, W, H, tiling=None, camera_model=0, repeat=1):
+        rows = tr.tiling_rows(tiling, H) if tiling is not None else H
+        single, want_stats = [], {k: 0 for k in abi.STAT_FIELDS}
+        tr.enable_stats(True)
+        for g, pc in frames:
+            o = bufs(rows, W)
+            hp = {k: v.data_ptr() for k, v in o[1].items()}
+            if tiling is None:
+                tr.render_dev(sc, g, pc, W, H, o[0].data_ptr(), camera=camera_model, hit_ptrs=hp, stream=s)
+            else:
+                tr.render_tiled_dev(sc, g, pc, W, H, tiling, o[0].data_ptr(), camera=camera_model, hit_ptrs=hp, stream=s)
+            st = tr.stats()
+            for k in abi.STAT_FIELDS:
+                want_stats[k] += st[k]
+            single.append(o)
+        outs = [bufs(rows, W) for _ in frames]
+        fl = [(g, pc, o[0].data_ptr(), {k: v.data_ptr() for k, v in o[1].items()}) for (g, pc), o in zip(frames, outs)]
+        tr.render_batch_dev(sc, fl, W, H, tiling, camera=camera_model, stream=s)
+        assert tr.stats() == want_stats
+        tr.enable_stats(False)
+        for _ in range(repeat):   # uncounted: the instantiations the timed loops run (cost feedback for scenes of >= 2 tori)
+            for o in outs:
+                o[0].fill_(-5.0)
+            tr.render_batch_dev(sc, fl, W, H, tiling, camera=camera_model, stream=s)
+            torch.cuda.synchronize()
+            for i, (a, b) in enumerate(zip(outs, single)):
+                assert same(a, b), i
+
+    W, H = 200, 136
+    sc1 = camera.single_torus_scene()
+    moving = [(camera.globals_for((0.3 * i, 1.5 - 0.2 * i, -4.0 + 0.3 * i), (0.0, 0.0, 0.0), W, H), camera.baseline_push(1 + i % 5)) for i in range(5)]
+    check(sc1, moving, W, H)
+    check(sc1, moving[:1], W, H)                                         # a batch of one = the single-frame path
+    W = H = 256
+    til = abi.trt_tiling(8, 4, 1, 1)
+    frames = [(camera.baseline_camera(W, H), camera.baseline_push(d)) for d in (5, 1, 3, 5, 2, 4, 5, 5)]
+    check(sc1, frames, W, H, tiling=til)
+    check(sc1, frames[:3], W, H, tiling=abi.trt_tiling(8, 2, 0, 1))
+    tr.set_solver(abi.TRT_SOLVE_F64)
+    try:
+        check(camera.nested_tori_scene(), frames, W, H, repeat=2)
+        check(camera.nested_tori_scene(), frames[:4], W, H, tiling=til, repeat=2)
+    finally:
+        tr.set_solver(abi.TRT_SOLVE_F32)
+    # toroidal camera (per-tile classification), a rho sweep as in BEF/main.cpp:236-258: same eye and centre, other rho
+    Wt, Ht = 256, 128
+    sct, gt = camera.single_torus_scene(R=6.0, r=1.5, material=camera.PLASTIC), camera.toroidal_camera(Wt, Ht)
+    sweep = []
+    for i in range(4):
+        pc = camera.baseline_push(3)
+        pc.rho = 3.0 + 0.5 * i
+        sweep.append((gt, pc))
+    check(sct, sweep, Wt, Ht, camera_model=1)
+    # refusals: frames whose toroidal tables differ, too many / no frames, another variant or solver
+    o = bufs(Ht, Wt)
+    other = camera.toroidal_camera(Wt, Ht, center=(10.0, 0.0, 3.0))
+    with pytest.raises(TrtError) as e:
+        tr.render_batch_dev(sct, [(gt, sweep[0][1], o[0].data_ptr(), None), (other, sweep[0][1], o[0].data_ptr(), None)], Wt, Ht, camera=1, stream=s)
+    assert e.value.code == abi.TRT_E_INVALID and "one by one" in str(e.value)
+    tr.render_dev(sct, gt, sweep[0][1], Wt, Ht, o[0].data_ptr(), camera=1, stream=s)   # the ctx still renders
+    one = (moving[0][0], moving[0][1], o[0].data_ptr(), None)
+    for bad in ([], [one] * 9):
+        with pytest.raises(TrtError) as e:
+            tr.render_batch_dev(sc1, bad, 64, 64, stream=s)
+        assert e.value.code == abi.TRT_E_INVALID
+    tr.set_render_variant("persistent")
+    try:
+        with pytest.raises(TrtError):
+            tr.render_batch_dev(sc1, [one, one], 64, 64, stream=s)
+        tr.render_batch_dev(sc1, [one], 64, 64, stream=s)                # one frame: every variant
+    finally:
+        tr.set_render_variant("listed")
+    tr.set_solver(abi.TRT_SOLVE_FERRARI_F32)
+    try:
+        with pytest.raises(TrtError):
+            tr.render_batch_dev(sc1, [one, one], 64, 64, stream=s)
+    finally:
+        tr.set_solver(abi.TRT_SOLVE_F32)
+    torch.cuda.synchronize()
+
+
 def test_bench_line_has_what_the_driver_parses():
     """`python bench.py` as the driver runs it (N = 1, small K, no CPU baseline / secondary passes to keep it short): ONE
     JSON line with the contract's keys, `roofline` priced on the pass into four alternating output sets with the

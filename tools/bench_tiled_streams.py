@@ -19,6 +19,7 @@ ap.add_argument("--part", type=int, default=0)
 ap.add_argument("--streams", type=int, nargs="+", default=[1, 2, 3, 4])
 ap.add_argument("--frames", type=int, default=192, help="frames per batch (a multiple of every --streams value)")
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--batch", type=int, nargs="*", default=[], help="also: B frames per launch on ONE stream (trt_render_batch_dev)")
 ap.add_argument("--graph", action="store_true", help="replay each batch as one hipGraph")
 ap.add_argument("--both", action="store_true", help="eager and graph, interleaved rounds in one process")
 ap.add_argument("--scene", default="single", choices=["single", "nested"], help="nested: the eight nested tori of config 4")
@@ -31,14 +32,14 @@ g, pc = camera.baseline_camera(W, H), camera.baseline_push(5)
 n = a.parts
 G = trtd.default_group_rows(H, n, trtd.DEFAULT_CYCLES) if n > 1 else None
 cur = torch.cuda.current_stream()
-for K in a.streams:
-    F = a.frames - a.frames % K
+for K, B in [(k, 1) for k in a.streams] + [(1, b) for b in a.batch]:
+    F = a.frames - a.frames % (K * B)
     trs = [Tracer(0) for _ in range(K)]
     if a.f64:
         for tr_ in trs:
             tr_.set_solver(abi.TRT_SOLVE_F64)
-    frame = trtd.TiledFrame(trs, W, H, n, a.part, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz"), gather="none", group_rows=G)
-    for _ in range(2 * K):
+    frame = trtd.TiledFrame(trs, W, H, n, a.part, dev, want_hits=("t", "px", "py", "pz", "nx", "ny", "nz"), gather="none", group_rows=G, batch=B)
+    for _ in range(2 * K * B):
         frame.render(sc, g, pc, abi.TRT_CAMERA_PINHOLE, cur)
     frame.restart()
     modes = ["eager", "graph"] if a.both else (["graph"] if a.graph else ["eager"])
@@ -66,7 +67,7 @@ for K in a.streams:
             out[m].append((time.perf_counter() - t0) / F)
     for m in modes:
         us = statistics.median(out[m]) * 1e6
-        print(f"{a.scene}{' f64' if a.f64 else ''}: {n} parts, part {a.part}, {K} stream(s), {m}: {us:.1f} us per frame "
+        print(f"{a.scene}{' f64' if a.f64 else ''}: {n} parts, part {a.part}, {K} stream(s), {B} frame(s) per launch, {m}: {us:.1f} us per frame "
               f"(wall, batches of {F} frames, median of {a.rounds}; min {min(out[m]) * 1e6:.1f})", flush=True)
     frame.finish()
     del frame

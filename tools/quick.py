@@ -52,6 +52,11 @@ if "c3alt" in cases:
         r, h = ptrs[state["i"] & 3]; state["i"] += 1
         tr.render_dev(sc1, g, pc, W, W, r, hit_ptrs=h, stream=s.cuda_stream)
     show("C3 into 4 alternating output sets", timeit(alt), 44 * W * W)
+    if "partsalt" in cases:   # the two halves of the frame alone, without the reuse
+        for skip, nm in ((1, "C3 LIVE part alone, 4 alternating sets"), (2, "C3 CLEAR part alone, 4 alternating sets")):
+            os.environ["TRT_DEBUG_SKIP"] = str(skip); _tuning.reload(tr)
+            show(nm, timeit(alt), 44 * W * W)
+        os.environ.pop("TRT_DEBUG_SKIP"); _tuning.reload(tr)
     del sets
 if "parts" in cases:
     for skip, nm in ((1, "C3 LIVE part alone (CLEAR skipped)"), (2, "C3 CLEAR part alone (LIVE skipped)")):

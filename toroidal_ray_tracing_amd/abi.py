@@ -15,6 +15,7 @@ import numpy as np
 TRT_OK, TRT_E_INVALID, TRT_E_NO_DEVICE, TRT_E_HIP, TRT_E_SCENE, TRT_E_NOMEM = 0, -1, -2, -3, -4, -5
 TRT_MAX_TORI = 8
 TRT_MAX_MATERIALS = 8
+TRT_MAX_BATCH = 8
 TRT_CAMERA_PINHOLE, TRT_CAMERA_TOROIDAL = 0, 1
 TRT_CLASSIFY_AUTO, TRT_CLASSIFY_MACRO, TRT_CLASSIFY_TILE = -1, 0, 1
 TRT_SOLVE_F32, TRT_SOLVE_F64, TRT_SOLVE_DK_F32, TRT_SOLVE_DK_F64 = 0, 1, 2, 3
@@ -80,6 +81,12 @@ class trt_point(C.Structure):
 class trt_tiling(C.Structure):
     _fields_ = [("group_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32),
                 ("compact", C.c_uint32)]
+
+
+class trt_frame(C.Structure):
+    """One frame of a batch (trt_render_batch_dev): what differs from frame to frame in a frame loop."""
+    _fields_ = [("g", C.POINTER(trt_globals)), ("pc", C.POINTER(trt_push)), ("rgba_dev", C.c_void_p),
+                ("first_hit_dev", C.POINTER(trt_hits))]
 
 
 class trt_stats(C.Structure):

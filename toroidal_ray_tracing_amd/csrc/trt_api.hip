@@ -252,7 +252,7 @@ constexpr float kRad2Deg = 57.29577951308232f;     // GLSL degrees()
 // Per-frame part of the toroidal camera (BEF/shaders/raytrace.rgen:36-53) and the
 // per-column / per-row trigonometry of :25-28,56-57, evaluated once on the host.
 int build_toro(trt_ctx* ctx, const trt_globals& g, const trt_push& pc, uint32_t W, uint32_t H,
-               hipStream_t stream, ToroCam& out)
+               hipStream_t stream, ToroCam& out, bool must_match = false)
 {
   float eye[3];
   mat4_origin(g.viewInverse, eye);                                           // :36
@@ -277,6 +277,9 @@ int build_toro(trt_ctx* ctx, const trt_globals& g, const trt_push& pc, uint32_t 
   // bit-compare the angles so that a NaN frame (eye above centre) still caches
   const bool same = key.valid && key.W == W && key.H == H && !std::memcmp(&key.omega, &omega, 4)
                     && !std::memcmp(&key.theta, &theta, 4);
+  if(!same && must_match)
+    return fail(ctx, TRT_E_INVALID, "trt_render_batch: the frames of a batch must share the toroidal camera's eye and centre (the ctx holds "
+                "one set of trigonometry tables); render these frames one by one");
   if(!same && capturing(stream))
     return fail(ctx, TRT_E_INVALID, "toroidal camera: the trigonometry tables of this (W, H, centre, rho) frame are not on the "
                 "device yet and cannot be uploaded while the stream is being captured into a hipGraph (a replay would "
@@ -557,88 +560,111 @@ uint32_t tiling_rows(const trt_tiling& t, uint32_t H)
   return full * t.group_rows + extra;
 }
 
-int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
+// One frame (the trt_render*_dev entry points) or a batch of them (trt_render_batch_dev): validates, fills one RenderArgs
+// per frame — the lists, their counters and capacities are shared by the frames of a batch — and launches.
+int render_frames(trt_ctx* ctx, const trt_frame* frames, uint32_t n_frames, const trt_scene* scene,
                   uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, const trt_tiling* tiling,
-                  int camera, float* rgba, trt_hits* first_hit, trt_rendered_data* rendered, void* stream)
+                  int camera, trt_rendered_data* rendered, void* stream)
 {
   if(!ctx) return TRT_E_INVALID;
-  if(!g || !pc) return fail(ctx, TRT_E_INVALID, "trt_render: NULL globals or push constants");
+  if(!frames || n_frames < 1 || n_frames > TRT_MAX_BATCH)
+    return fail(ctx, TRT_E_INVALID, "trt_render_batch: %u frames (1..%d)", n_frames, TRT_MAX_BATCH);
   if(W == 0 || H == 0 || row_begin > row_end || row_end > H)
     return fail(ctx, TRT_E_INVALID, "trt_render: bad size/rows W=%u H=%u rows=[%u,%u)", W, H, row_begin, row_end);
   if((uint64_t)W * H > 0x7fffffffull)
     return fail(ctx, TRT_E_INVALID, "trt_render: W*H=%llu exceeds 2^31-1 pixels", (unsigned long long)W * H);
   if(camera != TRT_CAMERA_PINHOLE && camera != TRT_CAMERA_TOROIDAL)
     return fail(ctx, TRT_E_INVALID, "trt_render: unknown camera %d", camera);
-  if(((uintptr_t)rgba | (uintptr_t)rendered) & 15)
-    return fail(ctx, TRT_E_INVALID, "trt_render: the rgba image and the RenderedData buffer must be 16-byte aligned (they are written as float4)");
-  if(first_hit)
-  {
-    const void* hp[8] = {first_hit->t, first_hit->px, first_hit->py, first_hit->pz, first_hit->nx, first_hit->ny, first_hit->nz, first_hit->id};
-    for(const void* q : hp)
-      if((uintptr_t)q & 3)
-        return fail(ctx, TRT_E_INVALID, "trt_render: first-hit streams must be 4-byte aligned");
-  }
   if(tiling && (tiling->group_rows == 0 || tiling->n_parts == 0 || tiling->part >= tiling->n_parts))
     return fail(ctx, TRT_E_INVALID, "trt_render_tiled: bad tiling group_rows=%u n_parts=%u part=%u",
                 tiling->group_rows, tiling->n_parts, tiling->part);
+  for(uint32_t f = 0; f < n_frames; ++f)
+  {
+    const trt_frame& fr = frames[f];
+    if(!fr.g || !fr.pc) return fail(ctx, TRT_E_INVALID, "trt_render: NULL globals or push constants");
+    if(((uintptr_t)fr.rgba_dev | (uintptr_t)rendered) & 15)
+      return fail(ctx, TRT_E_INVALID, "trt_render: the rgba image and the RenderedData buffer must be 16-byte aligned (they are written as float4)");
+    if(fr.first_hit_dev)
+    {
+      const trt_hits* h = fr.first_hit_dev;
+      const void* hp[8] = {h->t, h->px, h->py, h->pz, h->nx, h->ny, h->nz, h->id};
+      for(const void* q : hp)
+        if((uintptr_t)q & 3)
+          return fail(ctx, TRT_E_INVALID, "trt_render: first-hit streams must be 4-byte aligned");
+    }
+  }
+  const bool batch = n_frames > 1;
+  if(batch && (ctx->variant != kRenderListed || ctx->precision > TRT_SOLVE_F64))
+    return fail(ctx, TRT_E_INVALID, "trt_render_batch: batches run the listed variant with the default solver (TRT_SOLVE_F32 / _F64) only; "
+                                    "render these frames one by one");
+  if(batch && W > 8u * 8191u)
+    return fail(ctx, TRT_E_INVALID, "trt_render_batch: W <= 65528 (a batch's tile lists pack the tile column in 13 bits)");
   const SceneK* Sp = nullptr;
   if(int rc = build_scene(ctx, scene, Sp)) return rc;
   const SceneK& S = *Sp;
   TRT_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  RenderArgs  a;
-  std::memset(&a, 0, sizeof a);
-  a.g = *g;
-  a.pc = *pc;
-  a.W = W; a.H = H; a.row_begin = row_begin; a.row_end = row_end;
-  a.tile_group = 1; a.tile_parts = 1; a.tile_part = 0; a.compact = 0;
-  a.n_local_rows = row_end - row_begin;
-  if(tiling)
-  {
-    a.row_begin = 0; a.row_end = H;
-    a.tile_group = tiling->group_rows; a.tile_parts = tiling->n_parts; a.tile_part = tiling->part;
-    a.compact = tiling->compact;
-    a.n_local_rows = tiling_rows(*tiling, H);
-  }
-  a.camera = camera;
-  a.rgba = rgba;
-  if(first_hit) a.hits = *first_hit;
-  a.rendered = rendered;
-  a.counters = ctx->d_queue;
-  a.counts   = ctx->d_queue + 32;
-  if(camera == TRT_CAMERA_TOROIDAL)
-    if(int rc = build_toro(ctx, *g, *pc, W, H, st, a.toro)) return rc;
-  if(ctx->stats_on)
-  {
-    TRT_HIP(ctx, launch_zero_words((unsigned int*)ctx->d_stats, 16, st));
-    a.stats           = ctx->d_stats;
-    ctx->stats_pixels = (uint64_t)a.n_local_rows * W;
-  }
   if(ctx->variant == kRenderPersistent && S.dk)
     return fail(ctx, TRT_E_INVALID, "trt_render: the persistent variant implements the default solver only; "
                                     "use the listed or static variant with TRT_SOLVE_DK_* / TRT_SOLVE_FERRARI_*");
-  if(ctx->variant != kRenderStatic)
+  RenderBatch B;
+  std::memset(&B, 0, sizeof B);
+  B.n_frames = n_frames;
+  uint32_t n_local_rows = row_end - row_begin;
+  if(tiling) n_local_rows = tiling_rows(*tiling, H);
+  const size_t n_tiles = (size_t)((W + 7) / 8) * ((n_local_rows + 7) / 8);              // per frame
+  const size_t n_macro = (size_t)(((W + 7) / 8 + 3) / 4) * ((n_local_rows + 7) / 8);    // per frame
+  const bool   lists   = ctx->variant != kRenderStatic;
+  if(lists)
   {
-    if(W > 8u * 65535u || a.n_local_rows > 8u * 32767u)
+    if(W > 8u * 65535u || n_local_rows > 8u * 32767u)
       return fail(ctx, TRT_E_INVALID, "trt_render: the tile lists pack tile coordinates in 16 + 15 bits (W <= 524280, rows <= 262136)");
-    const size_t n_tiles = (size_t)((W + 7) / 8) * ((a.n_local_rows + 7) / 8);
-    if(int rc = grow(ctx, ctx->d_tiles, 2 * n_tiles * sizeof(uint32_t), st)) return rc;
-    a.tiles_live  = (uint32_t*)ctx->d_tiles.p;
-    a.tiles_clear = a.tiles_live + n_tiles;
-    a.cap_live    = (uint32_t)n_tiles;
-    a.cap_clear   = (uint32_t)n_tiles;
-    // cost feedback of the listed kernel (scheduling only): one word per macro tile, zero when the buffer is new.  It pays
-    // where the cost of a tile varies much and the frame is bound by the tracing: eight nested tori −11 % (FP64) / −15 %
-    // (FP32); a single torus' frame is bound by its stores and LOSES 2–3 % to the bookkeeping — scenes of one torus go without
-    if(ctx->variant == kRenderListed && ctx->tn.heavy_x16 && (uint32_t)S.n_tori >= ctx->tn.heavy_min_tori)
+    if(n_tiles * n_frames > 0x7fffffffull)
+      return fail(ctx, TRT_E_INVALID, "trt_render_batch: %zu tiles in the batch exceed the tile lists", n_tiles * n_frames);
+    if(int rc = grow(ctx, ctx->d_tiles, 2 * n_tiles * n_frames * sizeof(uint32_t), st)) return rc;
+  }
+  // cost feedback of the listed kernel (scheduling only): one word per macro tile (and frame of a batch), zero when the buffer is
+  // new.  It pays where the cost of a tile varies much and the frame is bound by the tracing: eight nested tori −11 % (FP64) /
+  // −15 % (FP32); a single torus' frame is bound by its stores and LOSES 2–3 % to the bookkeeping — scenes of one torus go without
+  const bool cost_fb = lists && ctx->variant == kRenderListed && ctx->tn.heavy_x16 && (uint32_t)S.n_tori >= ctx->tn.heavy_min_tori;
+  if(cost_fb && ctx->d_cost.cap < n_macro * n_frames * sizeof(uint32_t))
+  {
+    if(int rc = grow(ctx, ctx->d_cost, n_macro * n_frames * sizeof(uint32_t), st)) return rc;
+    TRT_HIP(ctx, hipMemsetAsync(ctx->d_cost.p, 0, ctx->d_cost.cap, st));   // never inside a capture: grow() refuses there
+  }
+  uint32_t fine_any = 0;
+  for(uint32_t f = 0; f < n_frames; ++f)
+  {
+    const trt_frame& fr = frames[f];
+    RenderArgs& a = B.fr[f];
+    a.g = *fr.g;
+    a.pc = *fr.pc;
+    a.W = W; a.H = H; a.row_begin = row_begin; a.row_end = row_end;
+    a.tile_group = 1; a.tile_parts = 1; a.tile_part = 0; a.compact = 0;
+    a.n_local_rows = n_local_rows;
+    if(tiling)
     {
-      const size_t n_macro = (size_t)(((W + 7) / 8 + 3) / 4) * ((a.n_local_rows + 7) / 8);
-      if(ctx->d_cost.cap < n_macro * sizeof(uint32_t))
-      {
-        if(int rc = grow(ctx, ctx->d_cost, n_macro * sizeof(uint32_t), st)) return rc;
-        TRT_HIP(ctx, hipMemsetAsync(ctx->d_cost.p, 0, ctx->d_cost.cap, st));   // never inside a capture: grow() refuses there
-      }
-      a.tile_cost = (uint32_t*)ctx->d_cost.p;
+      a.row_begin = 0; a.row_end = H;
+      a.tile_group = tiling->group_rows; a.tile_parts = tiling->n_parts; a.tile_part = tiling->part;
+      a.compact = tiling->compact;
+    }
+    a.camera = camera;
+    a.rgba = fr.rgba_dev;
+    if(fr.first_hit_dev) a.hits = *fr.first_hit_dev;
+    a.rendered = rendered;
+    a.counters = ctx->d_queue;
+    a.counts   = ctx->d_queue + 32;
+    if(camera == TRT_CAMERA_TOROIDAL)
+      if(int rc = build_toro(ctx, *fr.g, *fr.pc, W, H, st, a.toro, f > 0)) return rc;
+    if(ctx->stats_on) a.stats = ctx->d_stats;
+    if(!lists) continue;
+    a.tiles_live  = (uint32_t*)ctx->d_tiles.p;
+    a.tiles_clear = a.tiles_live + n_tiles * n_frames;
+    a.cap_live    = (uint32_t)(n_tiles * n_frames);
+    a.cap_clear   = (uint32_t)(n_tiles * n_frames);
+    if(cost_fb)
+    {
+      a.tile_cost = (uint32_t*)ctx->d_cost.p + (size_t)f * n_macro;
       a.heavy_x16 = ctx->tn.heavy_x16;
     }
     // tile culling needs tiles that are 8 contiguous image rows; with a RenderedData export the listed
@@ -656,7 +682,7 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     {
       // a pinhole camera INSIDE the scene (eye within two bounding radii of a torus) sees it the same way
       float eye[3];
-      mat4_origin(g->viewInverse, eye);
+      mat4_origin(fr.g->viewInverse, eye);
       for(uint32_t i = 0; i < scene->n_tori; ++i)
       {
         const trt_torus& t = scene->tori[i];
@@ -667,26 +693,49 @@ int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const 
     }
     if(ctx->classify != TRT_CLASSIFY_AUTO) a.fine = (uint32_t)ctx->classify;
     if(ctx->tn.fine >= 0) a.fine = (uint32_t)ctx->tn.fine;
+    fine_any |= a.fine;
     a.debug_skip = ctx->tn.debug_skip;   // always 0 in the release build
     uintptr_t bits = 0;
     const void* hp[8] = {a.hits.t, a.hits.px, a.hits.py, a.hits.pz, a.hits.nx, a.hits.ny, a.hits.nz, a.hits.id};
     for(const void* q : hp) bits |= (uintptr_t)q;
     a.vec4_ok = (W % 4 == 0 && (bits & 15) == 0) ? 1u : 0u;
   }
-  TRT_HIP(ctx, launch_render(S, a, ctx->variant, ctx->n_cus, ctx->tn, st));
+  if(ctx->stats_on)
+  {
+    TRT_HIP(ctx, launch_zero_words((unsigned int*)ctx->d_stats, 16, st));
+    ctx->stats_pixels = (uint64_t)n_local_rows * W * n_frames;
+  }
+  if(batch)
+  {
+    for(uint32_t f = 0; f < n_frames; ++f) B.fr[f].fine = fine_any;   // one classification kernel for the whole batch
+    const uint64_t lanes = fine_any ? (uint64_t)n_macro * 4 : (uint64_t)n_macro;
+    B.per_frame = (uint32_t)((lanes + 63) / 64 * 64);
+    TRT_HIP(ctx, launch_render_batch(S, B, ctx->n_cus, ctx->tn, st));
+  }
+  else
+    TRT_HIP(ctx, launch_render(S, B.fr[0], ctx->variant, ctx->n_cus, ctx->tn, st));
   if(ctx->stats_on && !capturing(st))
   {
     TRT_HIP(ctx, hipEventRecord(ctx->ev_stats, st));
     ctx->ev_stats_set = true;
   }
-  if(ctx->variant != kRenderStatic && ctx->tn.debug_tiles)
+  if(lists && ctx->tn.debug_tiles)
   {
     unsigned int q[4];
     TRT_HIP(ctx, hipStreamSynchronize(st));
-    TRT_HIP(ctx, hipMemcpy(q, a.counts, sizeof q, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[trt] tiles: live=%u (heavy %u, mean cost %u ticks) clear=%u (cull=%u)\n", q[0], q[2], q[3], q[1], a.tile_cull);
+    TRT_HIP(ctx, hipMemcpy(q, B.fr[0].counts, sizeof q, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[trt] tiles: live=%u (heavy %u, mean cost %u ticks) clear=%u (cull=%u)\n", q[0], q[2], q[3], q[1], B.fr[0].tile_cull);
   }
   return TRT_OK;
+}
+
+int render_common(trt_ctx* ctx, const trt_globals* g, const trt_push* pc, const trt_scene* scene,
+                  uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, const trt_tiling* tiling,
+                  int camera, float* rgba, trt_hits* first_hit, trt_rendered_data* rendered, void* stream)
+{
+  if(!ctx) return TRT_E_INVALID;
+  const trt_frame one = {g, pc, rgba, first_hit};
+  return render_frames(ctx, &one, 1, scene, W, H, row_begin, row_end, tiling, camera, rendered, stream);
 }
 
 }  // namespace
@@ -713,6 +762,12 @@ extern "C" int trt_render_tiled_dev(trt_ctx* ctx, const trt_globals* g, const tr
 {
   if(ctx && !tiling) return fail(ctx, TRT_E_INVALID, "trt_render_tiled: NULL tiling");
   return render_common(ctx, g, pc, scene, W, H, 0, H, tiling, camera, rgba, first_hit, rendered, stream);
+}
+
+extern "C" int trt_render_batch_dev(trt_ctx* ctx, const trt_frame* frames, uint32_t n_frames, const trt_scene* scene,
+                                    uint32_t W, uint32_t H, const trt_tiling* tiling, int camera, void* stream)
+{
+  return render_frames(ctx, frames, n_frames, scene, W, H, 0, H, tiling, camera, nullptr, stream);
 }
 
 extern "C" int trt_render(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,

@@ -672,6 +672,31 @@ __device__ __forceinline__ size_t live_slot(uint32_t cap_live, uint32_t n_heavy,
 constexpr int kClassifyThreads = TRT_CLASSIFY_THREADS;
 constexpr uint32_t kMacroTiles = 4;  // a macro tile = 4 horizontally adjacent 8×8 tiles = 32×8 pixels
 
+// Tile-list entries.  One frame per launch: tx | ty << 16 [| miss flag] (tx < 2^16, ty < 2^15).  A batch of frames
+// (trt_render_batch_dev): tx | ty << 13 | frame << 28 [| miss flag] (tx < 2^13: W <= 65528).
+constexpr uint32_t kTileMissFlag = 0x80000000u;
+template <bool BATCH> struct TileCode;
+template <> struct TileCode<false> {
+  static __device__ __forceinline__ uint32_t pack(uint32_t tx, uint32_t ty, uint32_t) { return tx | (ty << 16); }
+  static __device__ __forceinline__ uint32_t x(uint32_t p) { return p & 0xffffu; }
+  static __device__ __forceinline__ uint32_t y(uint32_t p) { return (p >> 16) & 0x7fffu; }
+  static __device__ __forceinline__ uint32_t frame(uint32_t) { return 0u; }
+};
+template <> struct TileCode<true> {
+  static __device__ __forceinline__ uint32_t pack(uint32_t tx, uint32_t ty, uint32_t f) { return tx | (ty << 13) | (f << 28); }
+  static __device__ __forceinline__ uint32_t x(uint32_t p) { return p & 0x1fffu; }
+  static __device__ __forceinline__ uint32_t y(uint32_t p) { return (p >> 13) & 0x7fffu; }
+  static __device__ __forceinline__ uint32_t frame(uint32_t p) { return (p >> 28) & 7u; }
+};
+__device__ __forceinline__ uint32_t tile_x(uint32_t packed) { return TileCode<false>::x(packed); }
+__device__ __forceinline__ uint32_t tile_y(uint32_t packed) { return TileCode<false>::y(packed); }
+
+// The launch arguments of the frame a wave works on: the kernel's own RenderArgs, or frame f of a batch (f wave-uniform).
+__device__ __forceinline__ const RenderArgs& frame_args(const RenderArgs& a, uint32_t) { return a; }
+__device__ __forceinline__ const RenderArgs& frame_args(const RenderBatch& b, uint32_t f) { return b.fr[f]; }
+template <bool BATCH> struct LaunchArgs { typedef RenderArgs type; };
+template <> struct LaunchArgs<true> { typedef RenderBatch type; };
+
 // What the two classification kernels share.  Per lane: the LIVE tiles it contributes, as NORMAL ones in the low and as
 // HEAVY ones in the high half of ONE word (a wave holds at most 256 of either, a block 4,096: the halves never carry
 // into each other), its CLEAR macro tile, and the macro tile's previous cost.  Three wave scans (as many shuffles as two
@@ -746,18 +771,30 @@ __device__ __forceinline__ void classify_reserve(const RenderArgs& a, uint32_t (
 // A clear macro tile becomes ONE entry of the CLEAR list (written later with full-line
 // dwordx4 stores); any other macro tile contributes its 8×8 tiles to the LIVE list.
 // (Ordering the LIVE list heavy-tiles-first was tried: render +10 %, classify 8 → 26 µs.)
-template <bool FB>
-__global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const SceneK scene, const RenderArgs a)
+template <bool FB, bool BATCH = false>
+__global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const SceneK scene, const typename LaunchArgs<BATCH>::type args)
 {
   // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
   // per list per block of macro tiles (a returning atomic on a shared word costs ≈11 ns under
   // contention — MI355X_MICROARCH.md "dequeue" — so they must be rare).
   __shared__ uint32_t wave_cnt[kClassifyRows][kClassifyThreads / 64];
   __shared__ uint32_t block_base[kClassifyRows];
+  // a batch: args.per_frame lanes per frame (a multiple of 64: a wave belongs to ONE frame, so its frame's arguments
+  // stay scalar loads); lanes past the last frame take part in the scans and barriers with nothing to add
+  const uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t f = 0, t = lane_id;
+  bool in_batch = true;
+  if constexpr(BATCH)
+  {
+    f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane_id / args.per_frame));
+    t = lane_id - f * args.per_frame;
+    in_batch = f < args.n_frames;
+    if(!in_batch) f = 0;
+  }
+  const RenderArgs& a = frame_args(args, f);
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool     valid = t < macro_x * tiles_y;
+  const bool     valid = in_batch && t < macro_x * tiles_y;
   const uint32_t mx = t % macro_x, ty = t / macro_x;
   const uint32_t tx0 = mx * kMacroTiles;
   const uint32_t ntile = valid ? min(kMacroTiles, tiles_x - tx0) : 0u;   // 8×8 tiles inside the image
@@ -780,11 +817,11 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
   const unsigned int ticket = classify_ticket(a);
   const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1];
   if(clear && ic < a.cap_clear)
-    a.tiles_clear[ic] = tx0 | (ty << 16);
+    a.tiles_clear[ic] = TileCode<BATCH>::pack(tx0, ty, f);
   const uint32_t il = heavy ? block_base[2] + (wave_cnt[4][wave] >> 16) + (pre[0] >> 16) : block_base[0] + (wave_cnt[4][wave] & 0xffffu) + (pre[0] & 0xffffu);
   for(uint32_t j = 0; j < nlive; ++j)
     if(il + j < a.cap_live)
-      a.tiles_live[heavy ? a.cap_live - 1u - (il + j) : il + j] = (tx0 + j) | (ty << 16);
+      a.tiles_live[heavy ? a.cap_live - 1u - (il + j) : il + j] = TileCode<BATCH>::pack(tx0 + j, ty, f);
   classify_publish(a, ticket);
 }
 
@@ -794,25 +831,32 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_kernel(const S
 // tiles goes to the LIVE list, a clear one with kTileMissFlag set: the listed kernel writes its
 // miss records without tracing (the other kernels ignore the flag and trace it — same result).
 // (Ordering the LIVE list heavy-tiles-first was tried: render +10 %, classify 8 → 26 µs.)
-constexpr uint32_t kTileMissFlag = 0x80000000u;   // packed entry = tx | ty << 16 | flag; ty < 2^15
-__device__ __forceinline__ uint32_t tile_x(uint32_t packed) { return packed & 0xffffu; }
-__device__ __forceinline__ uint32_t tile_y(uint32_t packed) { return (packed >> 16) & 0x7fffu; }
 
-template <bool FB>
-__global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(const SceneK scene, const RenderArgs a)
+template <bool FB, bool BATCH = false>
+__global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(const SceneK scene, const typename LaunchArgs<BATCH>::type args)
 {
   // per-block counts, per-wave offsets inside the block's reservation: ONE device-scope atomic
   // per list per block (a returning atomic on a shared word costs ≈11 ns under contention —
   // MI355X_MICROARCH.md "dequeue" — so they must be rare).
   __shared__ uint32_t wave_cnt[kClassifyRows][kClassifyThreads / 64];
   __shared__ uint32_t block_base[kClassifyRows];
+  const uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t f = 0, t = lane_id;
+  bool in_batch = true;
+  if constexpr(BATCH)   // (see tile_classify_kernel)
+  {
+    f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane_id / args.per_frame));
+    t = lane_id - f * args.per_frame;
+    in_batch = f < args.n_frames;
+    if(!in_batch) f = 0;
+  }
+  const RenderArgs& a = frame_args(args, f);
   const uint32_t tiles_x = (a.W + 7) >> 3, tiles_y = (a.n_local_rows + 7) >> 3;
   const uint32_t macro_x = (tiles_x + kMacroTiles - 1) / kMacroTiles;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = t / kMacroTiles, j = t % kMacroTiles;      // macro tile, tile inside it
   const uint32_t mx = m % macro_x, ty = m / macro_x;
   const uint32_t tx = mx * kMacroTiles + j;
-  const bool     valid = ty < tiles_y && tx < tiles_x;
+  const bool     valid = in_batch && ty < tiles_y && tx < tiles_x;
   const bool     clear = valid && a.tile_cull && tile_is_clear<true>(scene, a, tx * 8, ty, 8);
   // all four tiles of the macro tile clear (tiles outside the image count as clear)
   uint32_t c4 = (clear || !valid) ? 1u : 0u;
@@ -823,7 +867,7 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(co
   const uint32_t nclear = (valid && macro_clear && j == 0) ? 1u : 0u;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // cost feedback: the macro tile's previous cost, read (and reset) by its first lane, shared by its four lanes
-  const uint32_t cost  = FB ? (uint32_t)__shfl((int)classify_take_cost(a, j == 0 && ty < tiles_y, m), (int)(lane & ~3u), 64) : 0u;
+  const uint32_t cost  = FB ? (uint32_t)__shfl((int)classify_take_cost(a, in_batch && j == 0 && ty < tiles_y, m), (int)(lane & ~3u), 64) : 0u;
   const bool     heavy = FB && nlive != 0u && classify_is_heavy(a, cost);
   const bool     first = nlive != 0u && j == 0;   // (tile 0 of a macro tile is always inside the image)
 
@@ -840,9 +884,9 @@ __global__ __launch_bounds__(kClassifyThreads) void tile_classify_fine_kernel(co
   const uint32_t ic = block_base[1] + wave_cnt[1][wave] + pre[1];
   const uint32_t il = heavy ? block_base[2] + (wave_cnt[4][wave] >> 16) + (pre[0] >> 16) : block_base[0] + (wave_cnt[4][wave] & 0xffffu) + (pre[0] & 0xffffu);
   if(nclear && ic < a.cap_clear)
-    a.tiles_clear[ic] = tx | (ty << 16);
+    a.tiles_clear[ic] = TileCode<BATCH>::pack(tx, ty, f);
   if(nlive && il < a.cap_live)
-    a.tiles_live[heavy ? a.cap_live - 1u - il : il] = tx | (ty << 16) | (clear ? kTileMissFlag : 0u);
+    a.tiles_live[heavy ? a.cap_live - 1u - il : il] = TileCode<BATCH>::pack(tx, ty, f) | (clear ? kTileMissFlag : 0u);
   classify_publish(a, ticket);
 }
 
@@ -877,7 +921,7 @@ enum : int { K_NONE = 0, K_CLOSEST = 1, K_SHADOW = 2 };
 // writes 8 full 128-B lines.  rgba takes 4 dwordx4 per lane, instruction j writing pixels
 // 8j + q: again 8 full lines per instruction.  (Narrow stores are what bounds a streaming
 // writer on this chip: a dword store of 8×32-B row pieces is issue-limited to ≈3 B/clk/CU.)
-__device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t packed, uint32_t lane)
+__device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t tx, uint32_t ty, uint32_t lane)
 {
   // The constants of the miss record are (re)materialised HERE on purpose: hoisted out of the
   // caller's tile loop they stay live across the whole solve, get spilled to scratch, and every
@@ -886,7 +930,7 @@ __device__ __forceinline__ uint32_t clear_macro(const RenderArgs& a, uint32_t pa
   float inf, zero, one;
   asm volatile("v_mov_b32 %0, 0x7f800000\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 1.0" : "=v"(inf), "=v"(zero), "=v"(one));
   const float4 c = make_float4(a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f, one);
-  const uint32_t x0 = tile_x(packed) * 8, ly = tile_y(packed) * 8 + (lane >> 3), q = lane & 7;
+  const uint32_t x0 = tx * 8, ly = ty * 8 + (lane >> 3), q = lane & 7;
   if(ly >= a.n_local_rows)
     return 0;
   const uint32_t y   = image_row(a, ly);
@@ -1000,7 +1044,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         settle_loads(live_cache, clear_cache);
       }
       const uint32_t packed = __builtin_amdgcn_readlane(clear_cache, k_clear & 63u);
-      n_primary += clear_macro(a, packed, lane) * (uint32_t)n_tori;
+      n_primary += clear_macro(a, tile_x(packed), tile_y(packed), lane) * (uint32_t)n_tori;
       ++k_clear;
       if(!(exhausted && !__any(inflight || kind != K_NONE)))
         break;
@@ -1237,13 +1281,18 @@ constexpr uint32_t kListedThreads = 256;   // block size of the listed kernel: s
 // each gets one wave less instead of scratch.
 // RD: the launch exports RenderedData (a.rendered != nullptr); every wave then owns a 4-KB LDS image.
 // FB: the launch takes part in the cost feedback (RenderArgs::tile_cost): heavy tiles first, every traced tile timed.
-template <class Real, bool STATS, bool DK, bool RD, bool FB = false>
-__global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64) - (STATS ? 1 : 0) - (RD ? 1 : 0))) void render_listed_kernel(const SceneK scene, const RenderArgs a_arg)
+// BATCH: the launch renders up to kMaxBatch frames (RenderBatch, trt_render_batch_dev): every list entry names its frame,
+// whose arguments the wave takes from the block's LDS copy of the batch.  The single-frame instantiations are the code they
+// were before batches existed.
+template <class Real, bool STATS, bool DK, bool RD, bool FB = false, bool BATCH = false>
+__global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVES : TRT_LISTED_WAVES_F64) - (STATS ? 1 : 0) - (RD ? 1 : 0))) void render_listed_kernel(const SceneK scene, const typename LaunchArgs<BATCH>::type args)
 {
+  static_assert(!(BATCH && (RD || DK)), "batches: default solver, no RenderedData");
   __shared__ SceneK     S;
-  __shared__ RenderArgs A_lds;
+  __shared__ RenderArgs A_lds[BATCH ? kMaxBatch : 1];
   __shared__ float4     rd_images[RD ? 4 : 1][RD ? 256 : 1];
   float4* const rd_tile = RD ? rd_images[threadIdx.x >> 6] : nullptr;
+  const RenderArgs& a_arg = frame_args(args, 0u);   // lists, counters and capacities are the same in every frame of a batch
   TRT_STAMP(0, wall_clock64());
   TRT_STAMP(3, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32));   // HW_ID, XCC_ID
   // list lengths as published by the classification, never beyond the lists' capacity; read through the kernel
@@ -1257,14 +1306,42 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     TRT_STAMP(2, wall_clock64());
     return;
   }
-  stage_block256(&S, &A_lds, scene, a_arg);
+  if constexpr(BATCH)
+  {
+    // the frames' arguments in use (124 dwords each) with every thread, the scene with the upper half of the block
+    constexpr uint32_t NA = sizeof(RenderArgs) / 4;
+    const uint32_t  n_words = args.n_frames * NA;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&args.fr[0]);
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(&A_lds[0]);
+#pragma unroll 1
+    for(uint32_t i = threadIdx.x; i < n_words; i += kListedThreads)
+      dst[i] = src[i];
+    if(threadIdx.x >= 128u)
+    {
+      const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(&scene);
+      uint32_t*       sdst = reinterpret_cast<uint32_t*>(&S);
+      const uint32_t  n = (uint32_t)scene.n_tori, nm = (uint32_t)scene.n_mat;
+      const uint32_t  c0 = 12, c1 = c0 + (scene.f64 ? 0u : 10u * n), c2 = c1 + (scene.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
+                     c4 = c3 + 11u * nm;
+#pragma unroll 1
+      for(uint32_t i = threadIdx.x - 128u; i < c4; i += 128u)
+      {
+        const uint32_t off = i < c0 ? i : i < c1 ? 12u + (i - c0) : i < c2 ? 92u + (i - c1) : i < c3 ? 252u + (i - c2) : 292u + (i - c3);
+        sdst[off] = ssrc[off];
+      }
+    }
+    __syncthreads();
+  }
+  else
+    stage_block256(&S, &A_lds[0], scene, args);
   TRT_STAMP(5, wall_clock64());
-  const RenderArgs& a = A_lds;
+  const RenderArgs& a0 = A_lds[0];
   const uint32_t lane    = threadIdx.x & 63;
   const uint32_t n_waves = gridDim.x * (kListedThreads / 64u);
   const uint32_t g_wave  = __builtin_amdgcn_readfirstlane(blockIdx.x * (kListedThreads / 64u) + (threadIdx.x >> 6));
   uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0;
   WorkCount wc;
+  typedef TileCode<BATCH> TC;
 
   // Wave g owns entries g, g+G, g+2G, … of both lists.  Lane k prefetches the wave's k-th
   // entry of the current batch of 64 (one gather load per list per batch) and entries are
@@ -1286,8 +1363,8 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     if((i & 63u) == 0)
     {
       const uint64_t e = entry + (uint64_t)lane * n_waves;
-      live_cache  = e < n_live ? ld1(a.tiles_live, FB ? live_slot(a.cap_live, n_heavy, e) : (size_t)e) : 0u;
-      clear_cache = e < n_clear ? ld1(a.tiles_clear, (size_t)e) : 0u;
+      live_cache  = e < n_live ? ld1(a0.tiles_live, FB ? live_slot(a0.cap_live, n_heavy, e) : (size_t)e) : 0u;
+      clear_cache = e < n_clear ? ld1(a0.tiles_clear, (size_t)e) : 0u;
       settle_loads(live_cache, clear_cache);
       if(i == 0) TRT_STAMP(1, wall_clock64());
     }
@@ -1295,22 +1372,24 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     // hoisted out of the loop they would be spilled, and a spill reload is a vector-memory load
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
-    if(own_clear && !TRT_SKIP(a, 1u))
+    if(own_clear && !TRT_SKIP(a0, 1u))
     {
       const uint32_t cpacked = __builtin_amdgcn_readlane(clear_cache, i & 63u);
-      n_primary += clear_macro(a, cpacked, ln) * (uint32_t)S.n_tori;
+      const RenderArgs& a = A_lds[TC::frame(cpacked)];
+      n_primary += clear_macro(a, TC::x(cpacked), TC::y(cpacked), ln) * (uint32_t)S.n_tori;
       if(RD)   // the four 8×8 tiles of the macro tile: primary rays + miss record, no solve
         for(uint32_t j = 0; j < kMacroTiles; ++j)
-          rd_miss_tile(a, rd_tile, tile_x(cpacked) + j, tile_y(cpacked), ln);
+          rd_miss_tile(a, rd_tile, TC::x(cpacked) + j, TC::y(cpacked), ln);
     }
-    if(own_live && !TRT_SKIP(a, 2u))
+    if(own_live && !TRT_SKIP(a0, 2u))
     {
       const uint32_t packed = __builtin_amdgcn_readlane(live_cache, i & 63u);
+      const RenderArgs& a = A_lds[TC::frame(packed)];
       const unsigned long long tile_t0 = FB ? wall_clock64() : 0ull;
       if(i == 0) TRT_STAMP(4, 0x100000000ull | packed);
-      const uint32_t x = tile_x(packed) * 8 + (ln & 7), ly = tile_y(packed) * 8 + (ln >> 3);
+      const uint32_t x = TC::x(packed) * 8 + (ln & 7), ly = TC::y(packed) * 8 + (ln >> 3);
       if(RD && (packed & kTileMissFlag))
-        rd_miss_tile(a, rd_tile, tile_x(packed), tile_y(packed), ln);
+        rd_miss_tile(a, rd_tile, TC::x(packed), TC::y(packed), ln);
       if(x < a.W && ly < a.n_local_rows)
       {
         if(packed & kTileMissFlag)
@@ -1332,16 +1411,16 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
       {
         const uint32_t ticks = (uint32_t)(wall_clock64() - tile_t0);
         if(ln == 0u)
-          atomicMax(&a.tile_cost[tile_y(packed) * ((((a.W + 7u) >> 3) + kMacroTiles - 1u) / kMacroTiles) + tile_x(packed) / kMacroTiles], ticks ? ticks : 1u);
+          atomicMax(&a.tile_cost[TC::y(packed) * ((((a.W + 7u) >> 3) + kMacroTiles - 1u) / kMacroTiles) + TC::x(packed) / kMacroTiles], ticks ? ticks : 1u);
       }
       if(RD && !(packed & kTileMissFlag))
-        rd_flush(a, rd_tile, tile_x(packed), tile_y(packed), ln);
+        rd_flush(a, rd_tile, TC::x(packed), TC::y(packed), ln);
     }
   }
   TRT_STAMP(2, wall_clock64());
-  if(STATS && a.stats)   // STATS = false: the counters are dead code (their VGPRs and increments vanish)
+  if(STATS && a0.stats)   // STATS = false: the counters are dead code (their VGPRs and increments vanish)
   {
-    block_add_stats(a.stats, n_primary, n_bounce, n_shadow, wc);
+    block_add_stats(a0.stats, n_primary, n_bounce, n_shadow, wc);
   }
 }
 
@@ -1850,6 +1929,39 @@ hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant
   else if(tw == 64) TRT_LAUNCH_STATIC(float, 64, false);
   else TRT_LAUNCH_STATIC(float, 8, false);
 #undef TRT_LAUNCH_STATIC
+  return hipGetLastError();
+}
+
+// A batch of frames with the listed kernel (trt_render_batch_dev): one classification over every frame's tiles, one
+// render kernel over the joint lists — the launch shape of one frame with as many tiles as all of them together.
+hipError_t launch_render_batch(const SceneK& scene, const RenderBatch& b, int n_cus, const Tuning& tn, hipStream_t stream)
+{
+  const RenderArgs& a = b.fr[0];
+  if(b.n_frames == 0 || a.n_local_rows == 0 || a.W == 0)
+    return hipSuccess;
+  if(scene.dk || a.rendered)
+    return hipErrorInvalidValue;   // (trt_api.hip refuses these before)
+  const uint64_t tiles = (uint64_t)((a.W + 7) / 8) * ((a.n_local_rows + 7) / 8) * b.n_frames;
+  const uint64_t lanes = (uint64_t)b.per_frame * b.n_frames;
+  const bool fb = a.tile_cost != nullptr && a.heavy_x16 != 0u && a.stats == nullptr;
+  const dim3 cgrid((uint32_t)((lanes + kClassifyThreads - 1) / kClassifyThreads));
+  if(a.fine && fb) hipLaunchKernelGGL((tile_classify_fine_kernel<true, true>), cgrid, dim3(kClassifyThreads), 0, stream, scene, b);
+  else if(a.fine) hipLaunchKernelGGL((tile_classify_fine_kernel<false, true>), cgrid, dim3(kClassifyThreads), 0, stream, scene, b);
+  else if(fb) hipLaunchKernelGGL((tile_classify_kernel<true, true>), cgrid, dim3(kClassifyThreads), 0, stream, scene, b);
+  else hipLaunchKernelGGL((tile_classify_kernel<false, true>), cgrid, dim3(kClassifyThreads), 0, stream, scene, b);
+  uint64_t lcap = tiles / 16 > (uint64_t)n_cus * 4 ? tiles / 16 : (uint64_t)n_cus * 4;   // as launch_render: one wave per 16 tiles
+  if(tn.listed_blocks) lcap = tn.listed_blocks;
+  constexpr uint32_t wpb = kListedThreads / 64;
+  const uint32_t lgrid = (uint32_t)((tiles + wpb - 1) / wpb < lcap ? (tiles + wpb - 1) / wpb : lcap);
+#define TRT_LAUNCH_BATCH(REAL)                                                                                                        \
+  do {                                                                                                                                \
+    if(fb) hipLaunchKernelGGL((render_listed_kernel<REAL, false, false, false, true, true>), dim3(lgrid), dim3(kListedThreads), 0, stream, scene, b);      \
+    else if(a.stats) hipLaunchKernelGGL((render_listed_kernel<REAL, true, false, false, false, true>), dim3(lgrid), dim3(kListedThreads), 0, stream, scene, b);  \
+    else hipLaunchKernelGGL((render_listed_kernel<REAL, false, false, false, false, true>), dim3(lgrid), dim3(kListedThreads), 0, stream, scene, b);       \
+  } while(0)
+  if(scene.f64) TRT_LAUNCH_BATCH(double);
+  else TRT_LAUNCH_BATCH(float);
+#undef TRT_LAUNCH_BATCH
   return hipGetLastError();
 }
 

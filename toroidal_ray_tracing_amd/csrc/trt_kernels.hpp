@@ -50,6 +50,18 @@ struct RenderArgs {
   uint32_t            vec4_ok;      // W % 4 == 0 and all first-hit streams 16-B aligned: dwordx4 clears
 };
 
+// A batch of frames rendered by ONE pair of launches (trt_render_batch_dev): the frames share the scene, the size, the
+// tiling, the camera model, the tile lists and their counters; everything else — uniforms, push constants, toroidal
+// frame, output pointers, cost words — is per frame.  Tile-list entries of a batch carry the frame in three bits
+// (TileCode<true> in trt_kernels.hip).  per_frame: classification lanes per frame, a multiple of 64, so that a wave of
+// the classification kernels belongs to one frame.
+constexpr uint32_t kMaxBatch = TRT_MAX_BATCH;
+struct RenderBatch {
+  uint32_t   n_frames;
+  uint32_t   per_frame;
+  RenderArgs fr[kMaxBatch];
+};
+
 // Launch-shape knobs.  The release library uses the defaults below; a -DTRT_TUNING build
 // (libtrt_tuning.so, tools/ only) reads each of them ONCE from the environment in trt_create.
 struct Tuning {
@@ -100,5 +112,8 @@ hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, const Tuning& t
 hipError_t launch_zero_words(unsigned int* words, uint32_t n, hipStream_t stream);   // n <= 64
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus, const Tuning& tn,
                          hipStream_t stream);
+// listed variant, default solver, no RenderedData: b.fr[0 .. n_frames) filled like the RenderArgs of launch_render, with
+// the SAME lists / counters / capacities in every frame (capacities = tiles of all frames together)
+hipError_t launch_render_batch(const SceneK& scene, const RenderBatch& b, int n_cus, const Tuning& tn, hipStream_t stream);
 
 }  // namespace trt

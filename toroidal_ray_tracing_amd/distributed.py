@@ -88,7 +88,7 @@ class TiledFrame:
     """
 
     def __init__(self, tracer, W, H, world, rank, device, want_hits=(), group_rows=None,
-                 gather=True, force_collective=False, gather_every=1, output_sets=1):
+                 gather=True, force_collective=False, gather_every=1, output_sets=1, batch=1):
         """tracer: one Tracer, or a list of K of them (K render streams, one context each).
         gather: True / "fp32" — all-gather the rgba32f framebuffer (default, what north_star
         prescribes); "rgba8" — tonemap each rank's rows (trt_post_dev, post.frag) and all-gather
@@ -98,7 +98,9 @@ class TiledFrame:
         frame (frames F-1, 2F-1, …).  output_sets: M > K rotates the frames over M output sets (rounded up to a multiple
         of the K streams, so that a set always belongs to one stream) — consecutive frames then never write the same
         buffers and nothing of a frame is still in the 256-MB Infinity Cache when it is written again (bench.py's
-        roofline pass)."""
+        roofline pass).  batch: B > 1 collects B consecutive frames and renders them with ONE pair of launches
+        (trt_render_batch_dev; one tracer / one stream): B parts of a frame are the work of B/N full frames — a launch
+        that fills the chip where a single 1/N part does not.  The output sets are then at least B."""
         self.trs = list(tracer) if isinstance(tracer, (list, tuple)) else [tracer]
         self.tr = self.trs[0]
         self.W, self.H, self.world, self.rank = W, H, world, rank
@@ -120,9 +122,15 @@ class TiledFrame:
         self.local_pixels = self.local_rows * W
         self.device = torch.device(device)
         K = len(self.trs)
+        self.batch = max(1, int(batch))
+        if self.batch > 1 and K != 1:
+            raise ValueError("batch > 1 renders on one stream with one tracer")
+        if self.batch > abi.TRT_MAX_BATCH:
+            raise ValueError(f"batch={self.batch} > TRT_MAX_BATCH")
+        self._queued = []          # batch mode: (g, pc, output set, gather?) of the frames not yet launched
         f32 = dict(dtype=torch.float32, device=device)
         # one output set per render stream, or more (output_sets): frame i renders on stream i % K into set i % n_sets
-        self.n_sets = ((max(K, int(output_sets)) + K - 1) // K) * K
+        self.n_sets = ((max(K, self.batch, int(output_sets)) + K - 1) // K) * K
         self.locals = [torch.empty(self.local_rows, W, 4, **f32) for _ in range(self.n_sets)]
         self.hit_sets = []
         for _ in range(self.n_sets):
@@ -166,6 +174,8 @@ class TiledFrame:
         tail = (f"{self.cycles} x {what} {when}, each landing in place in the row-major frame, pipelined behind {behind}"
                 if self.gather else "no gather")
         k = f"; {len(self.trs)} frames in flight on {len(self.trs)} streams" if len(self.trs) > 1 else ""
+        if self.batch > 1:
+            k = f"; {self.batch} frames per launch (trt_render_batch_dev)"
         return f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; {tail}{k}"
 
     def _on(self, stream):
@@ -191,6 +201,14 @@ class TiledFrame:
         o = self._k % self.n_sets   # output set; n_sets is a multiple of K, so set o is only ever written on stream k
         self._k += 1
         self._caller = stream
+        if self.batch > 1:
+            self._camera, self._scene = camera, scene
+            self._queued.append((g, pc, o, self.gather and self._k % self.gather_every == 0))
+            if len(self._queued) == self.batch:
+                self.flush(stream)
+            if not self.gather:
+                self._last = o
+            return
         if self._own is not None:
             if not self._forked:
                 if self.device.type == "cuda":
@@ -215,6 +233,19 @@ class TiledFrame:
             self._gather(o, s, tr)
         if not self.gather:
             self._last = o
+
+    def flush(self, stream=None):
+        """Batch mode: launch the frames collected so far (a full batch launches by itself)."""
+        stream = stream or self._caller
+        if not self._queued:
+            return
+        q, self._queued = self._queued, []
+        frames = [(g, pc, self.locals[o].data_ptr(), {n: v.data_ptr() for n, v in self.hit_sets[o].items()}) for g, pc, o, _ in q]
+        self.tr.render_batch_dev(self._scene, frames, self.W, self.H, self.tiling if self.world > 1 else None, camera=self._camera,
+                                 stream=stream.cuda_stream)
+        for _, _, o, do_gather in q:
+            if do_gather:
+                self._gather(o, stream, self.tr)
 
     def _gather(self, o, s, tr):
         """Copy or tonemap output set o into a staging buffer on stream s and start the all-gathers behind that."""
@@ -257,7 +288,16 @@ class TiledFrame:
             if self._own is not None:
                 for s in self._own:
                     s.wait_stream(side)
-            for f in range(n_frames):
+            if self.batch > 1:
+                if n_frames % self.batch:
+                    raise ValueError("a captured step must consist of whole batches")
+                self._caller = side
+                for f in range(n_frames):
+                    self._queued.append((g, pc, f % self.n_sets, False))
+                    self._camera, self._scene = camera, scene
+                    if len(self._queued) == self.batch:
+                        self.flush(side)
+            for f in range(n_frames if self.batch == 1 else 0):
                 k, o = f % K, f % self.n_sets
                 s = self._own[k] if self._own is not None else side
                 hp = {n: v.data_ptr() for n, v in self.hit_sets[o].items()}
@@ -290,6 +330,8 @@ class TiledFrame:
         """K own streams: order `stream` (default: the stream of the last render call) behind every frame issued so far;
         the next render() branches off again."""
         stream = stream or self._caller
+        if self.batch > 1 and stream is not None:
+            self.flush(stream)
         if self._own is not None and self._forked and stream is not None:
             if self.device.type == "cuda":
                 for s in self._own:

@@ -34,6 +34,8 @@ SYMBOLS = {
                                        C.POINTER(abi.trt_scene), C.c_uint32, C.c_uint32,
                                        C.POINTER(abi.trt_tiling), C.c_int, C.c_void_p,
                                        C.POINTER(abi.trt_hits), C.c_void_p, C.c_void_p]),
+    "trt_render_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(abi.trt_frame), C.c_uint32, C.POINTER(abi.trt_scene), C.c_uint32,
+                                       C.c_uint32, C.POINTER(abi.trt_tiling), C.c_int, C.c_void_p]),
     "trt_tiling_rows": (C.c_uint32, [C.POINTER(abi.trt_tiling), C.c_uint32]),
     "trt_post_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trt_splat_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, abi.f32p, C.c_uint32, C.c_uint32, abi.f32p,

@@ -129,6 +129,23 @@ class Tracer:
                                                  C.c_void_p(int(rendered_ptr) or None),
                                                  C.c_void_p(int(stream) or None)))
 
+    def render_batch_dev(self, scene, frames, W, H, tiling=None, camera=abi.TRT_CAMERA_PINHOLE, stream=0):
+        """Up to TRT_MAX_BATCH consecutive frames of a frame loop in ONE pair of launches (trt_render_batch_dev).
+        frames: sequence of (g, pc, rgba_ptr, hit_ptrs | None); tiling None = whole frames."""
+        n = len(frames)
+        arr = (abi.trt_frame * n)()
+        keep = []
+        for dst, (g, pc, rgba_ptr, hit_ptrs) in zip(arr, frames):
+            dst.g, dst.pc = C.pointer(g), C.pointer(pc)
+            dst.rgba_dev = int(rgba_ptr) or None
+            if hit_ptrs:
+                hs = abi.hits_struct({k: (int(v) if v else None) for k, v in hit_ptrs.items()})
+                keep.append(hs)
+                dst.first_hit_dev = C.pointer(hs)
+        self._check(self._L.trt_render_batch_dev(self._h, arr, n, C.byref(scene.c), W, H,
+                                                 C.byref(tiling) if tiling is not None else None, camera,
+                                                 C.c_void_p(int(stream) or None)))
+
     def tiling_rows(self, tiling, H):
         return int(self._L.trt_tiling_rows(C.byref(tiling), H))
 
