@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--parts", type=int, default=8)
 ap.add_argument("--part", type=int, default=0)
-ap.add_argument("--streams", type=int, nargs="+", default=[1, 2, 3, 4])
+ap.add_argument("--streams", type=int, nargs="*", default=[1, 2, 3, 4])
 ap.add_argument("--frames", type=int, default=192, help="frames per batch (a multiple of every --streams value)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--batch", type=int, nargs="*", default=[], help="also: B frames per launch on ONE stream (trt_render_batch_dev)")

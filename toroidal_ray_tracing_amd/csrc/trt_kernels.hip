@@ -1548,24 +1548,33 @@ __global__ __launch_bounds__(256) void splat_points_kernel(const trt_point* __re
 // 2 ms for 8.4 M random points).  Here the screen is cut into bins of 128 × 64 pixels — 8,192 keys = 64 KB, one
 // LDS image — and the points are first sorted by bin:
 //   count    every block projects its chunk of points ONCE — the 8-B result {depth24, pixel rectangle} goes to a
-//            side array — and histograms it over the bins in LDS, one global add per non-empty bin;
-//   scan     exclusive prefix of the bin counts (one block);
-//   scatter  the same chunks again, from the side array (two sweeps, L2-resident): a block reserves one range
-//            per bin (one global add), its points take their ranks from an LDS counter and write 16-B records
-//            {point index, depth24, rectangle inside the bin};
+//            side array — and histograms it over the bins in LDS, one global add per non-empty bin; the block that
+//            finishes LAST (a ticket) turns the bin counts into their exclusive prefix (no scan launch);
+//   scatter  the chunks again, from the side array, ONE sweep: a block histograms its 4,096 points in LDS, reserves
+//            one range per bin (one global add), SORTS its records by bin in an LDS staging area and writes them out
+//            in sorted order — a wave's store instruction covers 768 contiguous bytes of a few bin runs instead of
+//            64 records at 64 unrelated addresses (round 2: 16-B records written one by one, each 32-B sector of
+//            HBM written twice — 273 MB of writes for 134 MB of records);
 //   resolve  ONE block per bin: atomicMin of the keys in LDS (ds_min_u64), then every pixel of the bin is written
 //            once — colour of the winning point, or the clear colour.
+// Records are 12 B: {point index, depth24, rectangle inside the bin (4 × 7 bits)}.
 // The keys, and so the image, are those of the one-pass form bit for bit (a minimum does not depend on the
 // order of its operands).  A point wider than a bin edge would need more than 4 records: such sizes, and images
 // with more than kSplatMaxBins bins, take the one-pass form.
 constexpr uint32_t kBinW = 128, kBinH = 64, kSplatMaxBins = 8192, kSplatChunk = 8192, kSplatMaxDim = 16383;
+constexpr uint32_t kSplatTicketWord = 3 * kSplatMaxBins;   // bin_words[…]: blocks of `count` that have finished (zero between calls)
+
+struct SplatRec { uint32_t idx, z, rect; };   // rect = rx0 | rx1 << 7 | ry0 << 15 | ry1 << 21  (bin-relative, half-open)
 
 struct SplatBins {
   uint32_t  bins_x, bins_y, n_bins;
   uint32_t* count;    // [n_bins]   points per bin: accumulated by `count`, zeroed again by `resolve`
-  uint32_t* offset;   // [n_bins]   first record of the bin (scan)
-  uint32_t* cursor;   // [n_bins]   records handed out so far (zeroed by scan)
-  uint4*    records;  // [<= 4 · n_points]
+  uint32_t* offset;   // [n_bins]   first record of the bin (written by the last block of `count`)
+  uint32_t* cursor;   // [n_bins]   records handed out so far (zeroed with the offsets)
+  uint32_t* ticket;   // blocks of `count` that have finished
+  uint32_t* table;    // [chunks of 4,096 points][n_bins] (sorted scatter only): where in its bin's range a chunk's records start —
+                      // what `count`'s returning add on the bin's count word returned; nullptr: `scatter` draws from `cursor`
+  SplatRec* records;  // [<= 4 · n_points]
   uint2*    proj;     // [n_points] the projected points (count → scatter)
 };
 
@@ -1583,6 +1592,10 @@ __device__ __forceinline__ bool splat_unpack(uint2 p, uint32_t& z24, int& x0, in
   z24 = p.y & 0xffffffu;
   return w != 0u;
 }
+__device__ __forceinline__ uint32_t splat_rect(int rx0, int rx1, int ry0, int ry1)
+{
+  return (uint32_t)rx0 | ((uint32_t)rx1 << 7) | ((uint32_t)ry0 << 15) | ((uint32_t)ry1 << 21);
+}
 
 // calls f(bin, x0r, x1r, y0r, y1r) for every bin the rectangle touches, rectangle clipped to the bin, bin-relative
 template <class F>
@@ -1597,41 +1610,89 @@ __device__ __forceinline__ void splat_for_bins(const SplatBins& b, int x0, int x
     }
 }
 
-__global__ __launch_bounds__(256) void splat_count_kernel(const trt_point* __restrict__ pts, uint64_t n, const SplatArgs a, const SplatBins b)
+// M sub-chunks of SUB points per block, 256 threads each (blockDim.x = M·256).  The direct scatter (M = 1, SUB = kSplatChunk)
+// only needs the bins' totals.  The sorted scatter (TABLE: SUB = its chunk of 4,096 points, M = 4) also needs to know where in
+// a bin's range each of ITS chunks starts: the block keeps one histogram per sub-chunk, adds their sum to the bin's count word
+// with ONE returning atomic — what comes back is the number of records earlier blocks have claimed — and writes the sub-chunks'
+// starts to table[chunk][bin]; the scatter then draws from no cursor at all (one million returning atomics less per call).
+template <uint32_t SUB, uint32_t M, bool TABLE>
+__global__ __launch_bounds__(M * 256) void splat_count_kernel(const trt_point* __restrict__ pts, uint64_t n, const SplatArgs a, const SplatBins b)
 {
-  extern __shared__ uint32_t hist[];
-  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x) hist[k] = 0u;
+  extern __shared__ uint32_t hist_all[];   // [M][n_bins]
+  __shared__ uint32_t part[256];
+  __shared__ int      is_last;
+  for(uint32_t k = threadIdx.x; k < M * b.n_bins; k += M * 256u) hist_all[k] = 0u;
   __syncthreads();
-  const uint64_t i0 = (uint64_t)blockIdx.x * kSplatChunk, i1 = min(n, i0 + kSplatChunk);
-  for(uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+  const uint32_t m = threadIdx.x >> 8, t = threadIdx.x & 255u;
+  uint32_t* hist = hist_all + m * b.n_bins;
+  const uint64_t i0 = ((uint64_t)blockIdx.x * M + m) * SUB, i1 = min(n, i0 + SUB);
+  // four points per lane and trip, their loads issued together (one 16-B load in flight per lane was latency-bound)
+  constexpr uint32_t U = 4;
+  for(uint64_t ib = i0 + t; ib < i1; ib += U * 256u)
   {
-    uint32_t z24;
-    int x0, x1, y0, y1;
-    uint2 pk = make_uint2(0u, 0u);
-    if(splat_project(reinterpret_cast<const float4*>(pts)[2 * i], a, z24, x0, x1, y0, y1))
+    float4 p[U];
+#pragma unroll
+    for(uint32_t u = 0; u < U; ++u)
     {
-      pk = splat_pack(z24, x0, x1, y0, y1);
-      splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int, int, int, int) { atomicAdd(&hist[bin], 1u); });
+      const uint64_t i = ib + u * 256u;
+      p[u] = i < i1 ? reinterpret_cast<const float4*>(pts)[2 * i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    b.proj[i] = pk;
+#pragma unroll
+    for(uint32_t u = 0; u < U; ++u)
+    {
+      const uint64_t i = ib + u * 256u;
+      if(i >= i1) continue;
+      uint32_t z24;
+      int x0, x1, y0, y1;
+      uint2 pk = make_uint2(0u, 0u);
+      if(splat_project(p[u], a, z24, x0, x1, y0, y1))
+      {
+        pk = splat_pack(z24, x0, x1, y0, y1);
+        splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int, int, int, int) { atomicAdd(&hist[bin], 1u); });
+      }
+      b.proj[i] = pk;
+    }
   }
   __syncthreads();
-  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x)
-    if(hist[k]) atomicAdd(&b.count[k], hist[k]);
-}
-
-__global__ __launch_bounds__(1024) void splat_scan_kernel(const SplatBins b)
-{
-  __shared__ uint32_t part[1024];
-  const uint32_t per = (b.n_bins + 1023u) / 1024u, k0 = threadIdx.x * per, k1 = min(b.n_bins, k0 + per);
-  uint32_t sum = 0;
-  for(uint32_t k = k0; k < k1; ++k) sum += b.count[k];
-  part[threadIdx.x] = sum;
+  // RETURNING adds: their results are back — the additions performed, at device scope — before the barrier in front of the
+  // block's ticket.  (No __threadfence(): an agent-scope release writes back the XCD's whole L2, the chunk's freshly written
+  // side array included — measured: the call 0.32 → 0.43 ms.)
+  uint32_t sink = 0;
+  for(uint32_t k = threadIdx.x; k < b.n_bins; k += M * 256u)
+  {
+    uint32_t c[M], total = 0;
+#pragma unroll
+    for(uint32_t j = 0; j < M; ++j) { c[j] = hist_all[j * b.n_bins + k]; total += c[j]; }
+    uint32_t run = total ? atomicAdd(&b.count[k], total) : 0u;
+    sink |= run;
+    if(TABLE)
+    {
+#pragma unroll
+      for(uint32_t j = 0; j < M; ++j)
+      {
+        b.table[((size_t)blockIdx.x * M + j) * b.n_bins + k] = run;
+        run += c[j];
+      }
+    }
+  }
+  if(sink == 0xffffffffu) part[threadIdx.x & 255u] = sink;   // (never true: a bin holds fewer than 2^32 records) keeps the results live
+  // the block that finishes last — every other block's additions are then performed — turns the counts into offsets
   __syncthreads();
+  if(threadIdx.x == 0)
+    is_last = atomicAdd(b.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if(!is_last || threadIdx.x >= 256u)
+    return;
+  const uint32_t per = (b.n_bins + 255u) / 256u, k0 = threadIdx.x * per, k1 = min(b.n_bins, k0 + per);
+  uint32_t sum = 0;
+  for(uint32_t k = k0; k < k1; ++k) sum += __hip_atomic_load(&b.count[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  part[threadIdx.x] = sum;
+  __syncthreads();   // (only the block's first 256 threads are left: four whole waves)
   if(threadIdx.x == 0)
   {
     uint32_t run = 0;
-    for(uint32_t t = 0; t < 1024u; ++t) { const uint32_t c = part[t]; part[t] = run; run += c; }
+    for(uint32_t q = 0; q < 256u; ++q) { const uint32_t c = part[q]; part[q] = run; run += c; }
+    *b.ticket = 0u;   // the next call counts its blocks from zero
   }
   __syncthreads();
   uint32_t run = part[threadIdx.x];
@@ -1639,40 +1700,149 @@ __global__ __launch_bounds__(1024) void splat_scan_kernel(const SplatBins b)
   {
     b.offset[k] = run;
     b.cursor[k] = 0u;
-    run += b.count[k];
+    run += __hip_atomic_load(&b.count[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-__global__ __launch_bounds__(256) void splat_scatter_kernel(uint64_t n, const SplatBins b)
+// scatter, sorted: up to kSortBins bins (2048: images up to 4096² and beyond), 4,096 points per block of 512 threads,
+// 12-B records staged in LDS in bin order.  LDS: 3 words per bin + 12 B per staged record = 78 KB: two blocks per CU.
+constexpr uint32_t kSortBins = 2048, kSortChunk = 4096, kSortThreads = 512, kSortPer = kSortChunk / kSortThreads, kSortStage = 4608;
+template <uint32_t NB>   // bins the block's LDS arrays hold: 512 (images up to 2048²: 61 KB of LDS) or kSortBins (79 KB)
+__global__ __launch_bounds__(kSortThreads) void splat_scatter_sorted_kernel(uint64_t n, const SplatBins b)
+{
+  __shared__ uint32_t hist[NB];    // points of this block per bin, then the rank counter
+  __shared__ uint32_t lbase[NB];   // first staged record of the bin
+  __shared__ uint32_t gbase[NB];   // first global record of this block's range in the bin
+  __shared__ SplatRec stage[kSortStage];  // records in bin order; the bin rides in the spare bits (z: 31..24, rect: 30..28)
+  __shared__ uint32_t wsum[kSortThreads / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  for(uint32_t k = tid; k < b.n_bins; k += kSortThreads) hist[k] = 0u;
+  __syncthreads();
+  const uint64_t i0 = (uint64_t)blockIdx.x * kSortChunk, i1 = min(n, i0 + kSortChunk);
+  uint2 pk[kSortPer];
+#pragma unroll
+  for(uint32_t u = 0; u < kSortPer; ++u)
+  {
+    const uint64_t i = i0 + u * kSortThreads + tid;
+    pk[u] = i < i1 ? b.proj[i] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for(uint32_t u = 0; u < kSortPer; ++u)
+  {
+    uint32_t z24;
+    int x0, x1, y0, y1;
+    if(splat_unpack(pk[u], z24, x0, x1, y0, y1))
+      splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int, int, int, int) { atomicAdd(&hist[bin], 1u); });
+  }
+  __syncthreads();
+  // exclusive prefix of the block's bin counts (the staging order) + one global reservation per non-empty bin
+  constexpr uint32_t kPerT = NB / kSortThreads;   // 1 or 4 consecutive bins per thread
+  uint32_t c[kPerT], mine = 0;
+#pragma unroll
+  for(uint32_t j = 0; j < kPerT; ++j)
+  {
+    const uint32_t k = tid * kPerT + j;
+    c[j] = k < b.n_bins ? hist[k] : 0u;
+    mine += c[j];
+  }
+  uint32_t inc = mine;
+#pragma unroll
+  for(int off = 1; off < 64; off <<= 1)
+  {
+    const uint32_t v = __shfl_up(inc, off, 64);
+    if(lane >= (uint32_t)off) inc += v;
+  }
+  if(lane == 63u) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = inc - mine;
+  for(uint32_t w = 0; w < wave; ++w) before += wsum[w];
+  uint32_t total = 0;
+  for(uint32_t w = 0; w < kSortThreads / 64; ++w) total += wsum[w];
+#pragma unroll
+  for(uint32_t j = 0; j < kPerT; ++j)
+  {
+    const uint32_t k = tid * kPerT + j;
+    if(k < b.n_bins)
+    {
+      lbase[k] = before;
+      gbase[k] = c[j] ? b.offset[k] + b.table[(size_t)blockIdx.x * b.n_bins + k] : 0u;   // (this chunk's start in the bin: `count`)
+      hist[k]  = 0u;
+      before += c[j];
+    }
+  }
+  __syncthreads();
+  // place: rank inside the bin from the LDS counter; records beyond the staging area (a chunk whose points straddle
+  // many bins) go straight to their place in global memory
+#pragma unroll
+  for(uint32_t u = 0; u < kSortPer; ++u)
+  {
+    uint32_t z24;
+    int x0, x1, y0, y1;
+    if(splat_unpack(pk[u], z24, x0, x1, y0, y1))
+    {
+      const uint32_t idx = (uint32_t)(i0 + u * kSortThreads + tid);
+      splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int rx0, int rx1, int ry0, int ry1) {
+        const uint32_t rank = atomicAdd(&hist[bin], 1u), slot = lbase[bin] + rank, rect = splat_rect(rx0, rx1, ry0, ry1);
+        if(slot < kSortStage)
+          stage[slot] = SplatRec{idx, z24 | (bin << 24), rect | ((bin >> 8) << 28)};
+        else
+          b.records[gbase[bin] + rank] = SplatRec{idx, z24, rect};
+      });
+    }
+  }
+  __syncthreads();
+  const uint32_t n_staged = umin(total, kSortStage);
+  for(uint32_t j = tid; j < n_staged; j += kSortThreads)
+  {
+    const SplatRec r = stage[j];
+    const uint32_t bin = (r.z >> 24) | ((r.rect >> 28) << 8);
+    b.records[gbase[bin] + (j - lbase[bin])] = SplatRec{r.idx, r.z & 0xffffffu, r.rect & 0x0fffffffu};
+  }
+}
+
+// scatter, direct (images of more than kSortBins bins): every record written at its place.  ONE sweep over the side array:
+// the block's 8,192 projected points stay in registers (16 per lane of 512, loaded together) between the counting and the
+// placing pass.
+constexpr uint32_t kDirectThreads = 512, kDirectPer = kSplatChunk / kDirectThreads;
+__global__ __launch_bounds__(kDirectThreads) void splat_scatter_kernel(uint64_t n, const SplatBins b)
 {
   extern __shared__ uint32_t lds[];
   uint32_t* hist = lds;             // [n_bins] points of this block per bin, then the rank counter
   uint32_t* base = lds + b.n_bins;  // [n_bins] first record of this block's range in the bin
-  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x) hist[k] = 0u;
+  for(uint32_t k = threadIdx.x; k < b.n_bins; k += kDirectThreads) hist[k] = 0u;
   __syncthreads();
   const uint64_t i0 = (uint64_t)blockIdx.x * kSplatChunk, i1 = min(n, i0 + kSplatChunk);
-  for(uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+  uint2 pk[kDirectPer];
+#pragma unroll
+  for(uint32_t u = 0; u < kDirectPer; ++u)
+  {
+    const uint64_t i = i0 + u * kDirectThreads + threadIdx.x;
+    pk[u] = i < i1 ? b.proj[i] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for(uint32_t u = 0; u < kDirectPer; ++u)
   {
     uint32_t z24;
     int x0, x1, y0, y1;
-    if(splat_unpack(b.proj[i], z24, x0, x1, y0, y1))
+    if(splat_unpack(pk[u], z24, x0, x1, y0, y1))
       splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int, int, int, int) { atomicAdd(&hist[bin], 1u); });
   }
   __syncthreads();
-  for(uint32_t k = threadIdx.x; k < b.n_bins; k += blockDim.x)
+  for(uint32_t k = threadIdx.x; k < b.n_bins; k += kDirectThreads)
   {
     base[k] = hist[k] ? b.offset[k] + atomicAdd(&b.cursor[k], hist[k]) : 0u;
     hist[k] = 0u;
   }
   __syncthreads();
-  for(uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+#pragma unroll
+  for(uint32_t u = 0; u < kDirectPer; ++u)
   {
     uint32_t z24;
     int x0, x1, y0, y1;
-    if(splat_unpack(b.proj[i], z24, x0, x1, y0, y1))
+    if(splat_unpack(pk[u], z24, x0, x1, y0, y1))
       splat_for_bins(b, x0, x1, y0, y1, [&](uint32_t bin, int rx0, int rx1, int ry0, int ry1) {
         const uint32_t rank = atomicAdd(&hist[bin], 1u);
-        b.records[base[bin] + rank] = make_uint4((uint32_t)i, z24, (uint32_t)rx0 | ((uint32_t)rx1 << 8) | ((uint32_t)ry0 << 16) | ((uint32_t)ry1 << 24), 0u);
+        b.records[base[bin] + rank] = SplatRec{(uint32_t)(i0 + u * kDirectThreads + threadIdx.x), z24, splat_rect(rx0, rx1, ry0, ry1)};
       });
   }
 }
@@ -1685,14 +1855,26 @@ __global__ __launch_bounds__(kSplatResolveThreads) void splat_resolve_bins_kerne
   for(uint32_t k = threadIdx.x; k < kBinW * kBinH; k += blockDim.x) keys[k] = kSplatClear;
   __syncthreads();
   const uint32_t bin = blockIdx.x, cnt = b.count[bin], off = b.offset[bin];
-  for(uint32_t r = threadIdx.x; r < cnt; r += blockDim.x)
+  // four records per lane and trip, their loads issued together
+  constexpr uint32_t kR = 4;
+  for(uint32_t rb = threadIdx.x; rb < cnt; rb += kR * blockDim.x)
   {
-    const uint4 rec = b.records[off + r];
-    const unsigned long long key = ((unsigned long long)rec.y << 32) | (unsigned long long)rec.x;
-    const uint32_t x0 = rec.z & 255u, x1 = (rec.z >> 8) & 255u, y0 = (rec.z >> 16) & 255u, y1 = rec.z >> 24;
-    for(uint32_t y = y0; y < y1; ++y)
-      for(uint32_t x = x0; x < x1; ++x)
-        atomicMin(&keys[y * kBinW + x], key);
+    SplatRec rec[kR];
+#pragma unroll
+    for(uint32_t u = 0; u < kR; ++u)
+    {
+      const uint32_t r = rb + u * blockDim.x;
+      rec[u] = r < cnt ? b.records[off + r] : SplatRec{0u, 0u, 0u};   // an empty rectangle
+    }
+#pragma unroll
+    for(uint32_t u = 0; u < kR; ++u)
+    {
+      const unsigned long long key = ((unsigned long long)rec[u].z << 32) | (unsigned long long)rec[u].idx;
+      const uint32_t x0 = rec[u].rect & 127u, x1 = (rec[u].rect >> 7) & 255u, y0 = (rec[u].rect >> 15) & 63u, y1 = (rec[u].rect >> 21) & 127u;
+      for(uint32_t y = y0; y < y1; ++y)
+        for(uint32_t x = x0; x < x1; ++x)
+          atomicMin(&keys[y * kBinW + x], key);
+    }
   }
   __syncthreads();
   if(threadIdx.x == 0) b.count[bin] = 0u;   // the next call counts from zero
@@ -1768,14 +1950,26 @@ hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp
     b.bins_x = (W + kBinW - 1) / kBinW; b.bins_y = (H + kBinH - 1) / kBinH; b.n_bins = sc.n_bins;
     // fixed layout whatever n_bins is: the count words of one call never alias another call's offsets
     b.count = sc.bin_words; b.offset = sc.bin_words + kSplatMaxBins; b.cursor = sc.bin_words + 2 * (size_t)kSplatMaxBins;
-    b.records = reinterpret_cast<uint4*>(sc.records);
+    b.ticket  = sc.bin_words + kSplatTicketWord;
+    b.records = reinterpret_cast<SplatRec*>(sc.records);
     b.proj    = reinterpret_cast<uint2*>(sc.proj);
+    b.table   = (sc.n_bins <= kSortBins && tn.splat_variant != 2) ? sc.table : nullptr;
     if(n_points)
     {
-      const uint32_t chunks = (uint32_t)((n_points + kSplatChunk - 1) / kSplatChunk);
-      hipLaunchKernelGGL(splat_count_kernel, dim3(chunks), dim3(256), sc.n_bins * sizeof(uint32_t), stream, pts, n_points, a, b);
-      hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, stream, b);
-      hipLaunchKernelGGL(splat_scatter_kernel, dim3(chunks), dim3(256), 2 * sc.n_bins * sizeof(uint32_t), stream, n_points, b);
+      const uint32_t chunks = (uint32_t)((n_points + kSplatChunk - 1) / kSplatChunk), schunks = (uint32_t)((n_points + kSortChunk - 1) / kSortChunk);
+      if(b.table)   // sorted scatter (sc.n_bins <= kSortBins)
+      {
+        hipLaunchKernelGGL((splat_count_kernel<kSortChunk, 4, true>), dim3((schunks + 3) / 4), dim3(1024), 4 * sc.n_bins * sizeof(uint32_t), stream, pts, n_points, a, b);
+        if(sc.n_bins <= 512u)
+          hipLaunchKernelGGL(splat_scatter_sorted_kernel<512>, dim3(schunks), dim3(kSortThreads), 0, stream, n_points, b);
+        else
+          hipLaunchKernelGGL(splat_scatter_sorted_kernel<kSortBins>, dim3(schunks), dim3(kSortThreads), 0, stream, n_points, b);
+      }
+      else
+      {
+        hipLaunchKernelGGL((splat_count_kernel<kSplatChunk, 1, false>), dim3(chunks), dim3(256), sc.n_bins * sizeof(uint32_t), stream, pts, n_points, a, b);
+        hipLaunchKernelGGL(splat_scatter_kernel, dim3(chunks), dim3(kDirectThreads), 2 * sc.n_bins * sizeof(uint32_t), stream, n_points, b);
+      }
     }
     hipLaunchKernelGGL(splat_resolve_bins_kernel, dim3(sc.n_bins), dim3(kSplatResolveThreads), 0, stream, pts, a, b,
                        make_float4(clear[0], clear[1], clear[2], clear[3]), reinterpret_cast<float4*>(rgba));
@@ -1816,11 +2010,15 @@ hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, const Tuning& t
 // Zeroes up to 64 words (the query counters of a counted launch) with a one-wave kernel: a kernel
 // node when the stream is being captured — the *_dev entry points put no memset node into a graph
 // (32 memset nodes between 64 kernel nodes faulted on replay under ROCm 7.2).
-__global__ void zero_words_kernel(unsigned int* q, uint32_t n) { if(threadIdx.x < n) q[threadIdx.x] = 0u; }
+__global__ void zero_words_kernel(unsigned int* q, uint32_t n)
+{
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = 0u;
+}
 
 hipError_t launch_zero_words(unsigned int* words, uint32_t n, hipStream_t stream)
 {
-  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, stream, words, n);
+  if(n <= 64u) hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, stream, words, n);
+  else hipLaunchKernelGGL(zero_words_kernel, dim3((n + 1023u) / 1024u < 64u ? (n + 1023u) / 1024u : 64u), dim3(1024), 0, stream, words, n);
   return hipGetLastError();
 }
 

@@ -95,13 +95,17 @@ constexpr int kPersistentBlocksPerCU = 16;  // 4× the resident 4 blocks/CU: the
 
 hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, const Tuning& tn,
                        hipStream_t stream);
-// Scratch of the re-projection: the binned form (n_bins != 0: 3·n_bins zero-initialised words + up to
-// 4·n_points 16-B records) or the one-pass form (keys: W·H 64-bit words).
+// Scratch of the re-projection: the binned form (n_bins != 0: kSplatBinWords zero-initialised words + up to
+// 4·n_points 12-B records) or the one-pass form (keys: W·H 64-bit words).
+constexpr size_t kSplatBinWords   = 3 * 8192 + 64;   // count / offset / cursor for the largest bin count, + the ticket word
+constexpr size_t kSplatRecordSize = 12;
+constexpr size_t kSplatSortBins = 2048, kSplatSortChunk = 4096;   // = kSortBins, kSortChunk of trt_kernels.hip
 struct SplatScratch {
   uint32_t            n_bins;
   uint32_t*           bin_words;
-  void*               records;   // 16 B x 4 n_points
+  void*               records;   // 12 B x 4 n_points
   void*               proj;      // 8 B x n_points
+  uint32_t*           table;     // (n_points / 4096 + 1) x n_bins words when n_bins <= 2048 (sorted scatter), else unused
   unsigned long long* keys;
 };
 uint32_t   splat_bins(uint32_t W, uint32_t H, float point_size, uint64_t n_points, const Tuning& tn);   // 0: one-pass form
@@ -109,7 +113,7 @@ hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp
                         const float* clear, float point_size, const SplatScratch& sc, float* rgba, int n_cus,
                         const Tuning& tn, hipStream_t stream);
 hipError_t launch_trace(const SceneK& scene, const TraceArgs& a, const Tuning& tn, hipStream_t stream);
-hipError_t launch_zero_words(unsigned int* words, uint32_t n, hipStream_t stream);   // n <= 64
+hipError_t launch_zero_words(unsigned int* words, uint32_t n, hipStream_t stream);
 hipError_t launch_render(const SceneK& scene, const RenderArgs& a, RenderVariant v, int n_cus, const Tuning& tn,
                          hipStream_t stream);
 // listed variant, default solver, no RenderedData: b.fr[0 .. n_frames) filled like the RenderArgs of launch_render, with
