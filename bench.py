@@ -100,7 +100,7 @@ def parse():
     ap.add_argument("--gather-every", default="step",
                     help="N>1: gather every K-th frame; 'step' (default) = once per step, the batch's last frame — the reference reads "
                          "its image back once per 60-frame batch (BEF/main.cpp:339-343,384-399); 1 = replicate every frame")
-    ap.add_argument("--group-rows", type=int, default=0, help="N>1: rows per interleaved group (0 = 8 cycles per frame)")
+    ap.add_argument("--group-rows", type=int, default=0, help="N>1: rows per interleaved group (0 = 16 groups per rank)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU rehearsal of the launcher and the gather (needs --dry-run)")
     ap.add_argument("--dry-run", action="store_true",

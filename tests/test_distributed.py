@@ -180,8 +180,8 @@ def test_bench_never_reports_the_wrong_job_size():
 
 def test_default_group_rows():
     assert trtd.default_group_rows(4096, 8, 1) == 512 and trtd.default_group_rows(4096, 2, 1) == 2048
-    assert trtd.default_group_rows(4096, 8) == 64 and trtd.default_group_rows(4096, 2) == 256
-    assert trtd.default_group_rows(8192, 8) == 128 and trtd.default_group_rows(4096, 1) == 4096
+    assert trtd.default_group_rows(4096, 8) == 32 and trtd.default_group_rows(4096, 2) == 128
+    assert trtd.default_group_rows(8192, 8) == 64 and trtd.default_group_rows(4096, 1) == 4096
     assert trtd.default_group_rows(64, 2) == 8 and trtd.default_group_rows(48, 3) == 8
     for H, N in [(4096, 8), (4096, 4), (4096, 2), (8192, 8), (64, 2), (48, 3)]:
         G = trtd.default_group_rows(H, N)

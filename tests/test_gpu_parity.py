@@ -421,7 +421,7 @@ def test_config4_full_size_properties(tr, variant):
 
 def test_config5_shape_tiled_on_one_gpu(tr):
     """BASELINE config 5's shape on ONE GPU: 8192², maxDepth 5, the 8 parts of `trt_tiling` (groups of 8 rows and the
-    default groups of 128 rows) rendered one after the other through trt_render_tiled_dev into compact buffers —
+    default groups of 64 rows) rendered one after the other through trt_render_tiled_dev into compact buffers —
     what the 8 ranks do.  The parts, put at their rows (the in-place gather of TiledFrame), equal the full-frame
     render bit for bit; plus the oracle-free properties of test_full_size_properties on the assembled frame."""
     import torch

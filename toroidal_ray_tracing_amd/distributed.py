@@ -15,9 +15,9 @@ gathered frame needs no de-interleaving copy (round 1 paid 2 × 268 MB of HBM tr
 for one).  How many cycles: when EVERY frame is gathered the step is bound by the collective, not by
 the render, so ONE cycle — plain row bands, one large collective per frame, no launch
 overhead of eight small ones (xGMI is point-to-point, 7 links per GPU; RCCL spreads a large
-collective over all of them); with a gather per batch, or none, eight cycles: an interleaving
+collective over all of them); with a gather per batch, or none, DEFAULT_CYCLES (16) cycles: an interleaving
 fine enough to balance the load (the torus sits in the middle rows), and the batch's frame is
-gathered group by group.
+gathered group by group (DEFAULT_CYCLES groups per rank).
 
 How often: `gather_every` = F gathers only every F-th frame — the frame that leaves the render loop.  The reference's
 loop renders 60 frames per camera radius and reads the image back once, after the 60th (BEF/main.cpp:339-343 `counter ==
@@ -30,7 +30,8 @@ import torch.distributed as dist
 
 from . import abi
 
-DEFAULT_CYCLES = 8          # groups per rank when the render binds the step: a gather per batch, or none (load balance)
+DEFAULT_CYCLES = 16         # groups per rank when the render binds the step: a gather per batch, or none (load balance:
+                            # the slowest of 8 parts is 91 / 93 / 94 % of linear with 8 / 16 / 32 groups per rank, tools/bench_tiled.py --batch)
 DEFAULT_CYCLES_GATHER = 1   # … and with a gather after EVERY frame: a single collective per frame
 
 
