@@ -438,6 +438,11 @@ def worker(a, world, rank, local):
 
     if a.backend != "nccl":
         raise SystemExit("--backend gloo is the CPU rehearsal: add --dry-run (a measurement needs the GPUs and RCCL)")
+    # stdout carries ONE line, the result.  RCCL prints a version banner on the process's stdout when the first communicator is
+    # created: from here on file descriptor 1 is stderr, and the result line goes to the descriptor that was stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if local >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
@@ -707,7 +712,8 @@ def worker(a, world, rank, local):
             cb = cpu_baseline(sc, g, pc, W, H)
             out["cpu_baseline_1thread"] = cb.pop("one_thread")
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -194,3 +194,151 @@ def closed_form_family(family, n, seed, C=(0.0, 0.0, 0.0), R=1.0, r=0.25, tmin=0
         q = np.stack([pl[:, 0] * R / rho, np.zeros(n), pl[:, 2] * R / rho], 1)
     N = (pl - q) / r
     return o.astype(np.float32), d.astype(np.float32), t, N, ok
+
+
+# ---------------------------------------------------------------------------------------------
+# Independent FP64 restatement of the shading chain (raygen → bounce loop → closest-hit shader)
+# ---------------------------------------------------------------------------------------------
+# Written from the GLSL, not from oracle/trt_oracle.c: numpy float64, vectorised over the pixels that are still
+# in the loop, first hits from the companion-matrix solver above, the shadow query as a first hit below the light
+# distance.  It shares no arithmetic with the C oracle or the kernels (which are FP32 with explicit fma and a
+# different root finder), so agreement on colours pins the control flow and the Phong chain, not only t and N.
+# Paths: vk_raytracing_tutorial_KHR/ray_tracing_reflections/shaders (REFL) and ray_tracing__before/shaders (BEF).
+def _normalize(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def _reflect(i, n):
+    """GLSL reflect(I, N) = I - 2 dot(N, I) N"""
+    return i - 2.0 * np.einsum("ni,ni->n", n, i)[:, None] * n
+
+
+def primary_rays(view_inverse, proj_inverse, center, rho, W, H, camera):
+    """(origin, direction) per pixel, row-major y*W+x.  view_inverse / proj_inverse: 4x4, math convention M[row, col].
+    camera 0: REFL/raytrace.rgen:42-48.  camera 1: BEF/raytrace.rgen:22-57 (angles in degrees, as there)."""
+    vi, pi_ = np.asarray(view_inverse, np.float64), np.asarray(proj_inverse, np.float64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    xs, ys = xs.reshape(-1).astype(np.float64), ys.reshape(-1).astype(np.float64)
+    n = W * H
+    if camera == 0:
+        dx, dy = (xs + 0.5) / W * 2.0 - 1.0, (ys + 0.5) / H * 2.0 - 1.0                       # rgen:42-44
+        origin = np.tile((vi @ np.array([0.0, 0.0, 0.0, 1.0]))[:3], (n, 1))                   # rgen:46
+        target = (pi_ @ np.stack([dx, dy, np.ones(n), np.ones(n)]))[:3].T                     # rgen:47
+        direction = (vi[:3, :3] @ _normalize(target).T).T                                     # rgen:48 (w = 0)
+        return origin, direction
+    eye = (vi @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]                                           # BEF rgen:36
+    c = np.asarray(center, np.float64)
+    tmp = c - eye                                                                             # :38
+    dir2 = np.array([tmp[0], tmp[2]]) / np.hypot(tmp[0], tmp[2])                              # :39
+    omega = np.degrees(np.arccos(dir2[0]))                                                    # :40
+    if tmp[2] < 0:
+        omega = 360.0 - omega                                                                 # :41-43
+    theta = 0.0
+    if eye[1] != c[1]:                                                                        # :45
+        first = np.array([eye[0] + rho * np.cos(np.radians(omega)), eye[1], eye[2] + rho * np.sin(np.radians(omega))])
+        tmp = c - first                                                                       # :46-47
+        theta = np.degrees(np.arccos(tmp[0] / np.hypot(tmp[0], tmp[1])))                      # :48-49
+        if tmp[1] < 0:
+            theta = 360.0 - theta                                                             # :50-52
+    alfa, beta = 360.0 / W * xs, 360.0 / H * ys                                               # :25-28
+    aw, bt = np.radians(alfa + omega), np.radians(beta + theta)
+    origin = np.stack([eye[0] + rho * np.cos(aw), np.full(n, eye[1]), eye[2] + rho * np.sin(aw)], 1)   # :56
+    direction = np.stack([np.cos(aw) * np.cos(bt), np.sin(bt), np.sin(aw) * np.cos(bt)], 1)           # :57
+    return origin, direction
+
+
+def shade_frame(tori, materials, view_inverse, proj_inverse, center, push, W, H, camera=0, tmin=0.001, tmax=10000.0):
+    """tori: [(C, R, r, matId)]; materials: [dict(ambient, diffuse, specular, shininess, illum)];
+    push: dict(clearColor(4), lightPosition(3), lightIntensity, lightType, maxDepth, rho).
+    Returns (rgba (H, W, 4) float64, robust (H, W) bool, queries dict): `robust` is False for a pixel any of whose queries
+    is sensitive to a 1e-4 perturbation (grazing hits, self-shadow terminators) or whose N·L is within 1e-3 of zero;
+    queries = closest-hit queries at depth 0 / at depth > 0 / shadow queries (rays, not ray–torus tests)."""
+    geo = [(np.asarray(C, np.float64), float(R), float(r)) for C, R, r, _ in tori]
+    mat_of = np.array([m for _, _, _, m in tori])
+    M = {k: np.array([np.asarray(m[k], np.float64) for m in materials]) for k in ("ambient", "diffuse", "specular")}
+    shin = np.array([float(m["shininess"]) for m in materials])
+    illum = np.array([int(m["illum"]) for m in materials])
+    clear = np.asarray(push["clearColor"], np.float64)[:3]
+    lp = np.asarray(push["lightPosition"], np.float64)
+    n = W * H
+    o, d = primary_rays(view_inverse, proj_inverse, center, float(push.get("rho", 0.0)), W, H, camera)
+    hit_value = np.zeros((n, 3))
+    attenuation = np.ones((n, 3))                                                             # rgen:56
+    robust = np.ones(n, bool)
+    live = np.arange(n)                                                                       # pixels still in the loop
+    queries = {"primary": 0, "bounce": 0, "shadow": 0}
+    for depth in range(int(push["maxDepth"])):                                                # rgen:62, :79
+        if len(live) == 0:
+            break
+        queries["primary" if depth == 0 else "bounce"] += len(live)
+        t, tid = first_hit(o, d, geo, tmin, tmax)                                             # rgen:64-75
+        robust[live] &= classify_margin(o, d, geo, tmin, tmax)
+        hit = ~np.isnan(t)
+        prd = np.tile(clear * 0.8, (len(live), 1))                                            # rmiss:37
+        done = np.ones(len(live), bool)                                                       # rgen:57 / :84
+        nxt_o, nxt_d = o.copy(), d.copy()
+        if hit.any():
+            ho, hd, ht, hid = o[hit], d[hit], t[hit], tid[hit]
+            P = ho + ht[:, None] * hd                                                         # BEF rchit:134
+            N = np.zeros_like(P)
+            for i, (C, R, r) in enumerate(geo):
+                sel = hid == i
+                if sel.any():
+                    N[sel] = normal(P[sel], C, R)                                             # role of rchit:74-75
+            if int(push["lightType"]) == 0:                                                   # rchit:82-88
+                ldir = lp - P
+                ldist = np.linalg.norm(ldir, axis=1)
+                lint = float(push["lightIntensity"]) / (ldist * ldist)
+                L = ldir / ldist[:, None]
+            else:                                                                             # rchit:89-92
+                L = np.tile(lp / np.linalg.norm(lp), (len(P), 1))
+                ldist = np.full(len(P), 100000.0)
+                lint = np.full(len(P), float(push["lightIntensity"]))
+            mi = mat_of[hid]                                                                  # rchit:95-96
+            ndl = np.einsum("ni,ni->n", N, L)
+            diffuse = M["diffuse"][mi] * np.maximum(ndl, 0.0)[:, None]                        # wavefront.glsl:25-26
+            diffuse = diffuse + np.where((illum[mi] >= 1)[:, None], M["ambient"][mi], 0.0)    # :27-28
+            specular = np.zeros_like(P)
+            att1 = np.ones(len(P))
+            want = ndl > 0                                                                    # rchit:112
+            hit_px = live[hit]
+            robust[hit_px] &= np.abs(ndl) > 1e-3
+            if want.any():
+                queries["shadow"] += int(want.sum())
+                so, sd = P[want], L[want]                                                     # rchit:116-117
+                shadowed = np.zeros(len(so), bool)
+                stable = np.ones(len(so), bool)
+                # one query per light distance would be exact; the distances differ per pixel, so: per-pixel tmax
+                ts, _ = first_hit(so, sd, geo, tmin, np.inf)
+                with np.errstate(invalid="ignore"):
+                    shadowed = ~np.isnan(ts) & (ts < ldist[want])                             # rchit:114-131, any hit below tMax
+                    # sensitivity: a first hit that moves across tmin or across the light distance, or appears / vanishes
+                    stable = classify_margin(so, sd, geo, tmin, np.inf) & ~(np.abs(ts - ldist[want]) < 1e-3)
+                robust[hit_px[want]] &= stable
+                att1[want] = np.where(shadowed, 0.3, 1.0)                                     # rchit:133-136
+                lit = np.flatnonzero(want)[~shadowed]
+                if len(lit):                                                                  # rchit:140 → wavefront.glsl:32-48
+                    ml = mi[lit]
+                    ks = np.maximum(shin[ml], 4.0)
+                    energy = (2.0 + ks) / (2.0 * 3.14159265)
+                    V = _normalize(-hd[lit])
+                    Rr = _reflect(-L[lit], N[lit])
+                    s = energy * np.power(np.maximum(np.einsum("ni,ni->n", V, Rr), 0.0), ks)
+                    specular[lit] = np.where((illum[ml] >= 2)[:, None], M["specular"][ml] * s[:, None], 0.0)
+            mirror = illum[mi] == 3                                                           # rchit:145
+            a_hit = attenuation[hit_px]
+            a_hit[mirror] *= M["specular"][mi][mirror]                                        # rchit:149
+            attenuation[hit_px] = a_hit
+            hdone = np.ones(len(P), bool)
+            hdone[mirror] = False                                                             # rchit:150
+            done[hit] = hdone
+            no, nd = ho.copy(), hd.copy()
+            no[mirror] = P[mirror]                                                            # rchit:147,151
+            nd[mirror] = _reflect(hd[mirror], N[mirror])                                      # rchit:148,152 (not re-normalised)
+            nxt_o[hit], nxt_d[hit] = no, nd
+            prd[hit] = (att1 * lint)[:, None] * (diffuse + specular)                          # rchit:155
+        hit_value[live] += prd * attenuation[live]                                            # rgen:76
+        keep = ~done                                                                          # rgen:79
+        live, o, d = live[keep], nxt_o[keep], nxt_d[keep]                                     # rgen:82-84
+    rgba = np.concatenate([hit_value, np.ones((n, 1))], 1).reshape(H, W, 4)                   # rgen:87
+    return rgba, robust.reshape(H, W), queries

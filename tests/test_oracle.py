@@ -392,3 +392,44 @@ def test_splat_order_independence_of_result(oracle):
     perm = np.random.default_rng(0).permutation(len(pts))
     b = oracle.splat(pts[perm], vp, W, H)
     assert (a != b).any(axis=2).mean() < 0.01   # only exact D24 ties may differ
+
+
+@pytest.mark.parametrize("name,cam", [("render_pinhole_mirror", abi.TRT_CAMERA_PINHOLE), ("render_pinhole_nested_f64", abi.TRT_CAMERA_PINHOLE),
+                                      ("render_toroidal_plastic", abi.TRT_CAMERA_TOROIDAL)])
+def test_shading_chain_vs_independent_fp64(name, cam):
+    """The colours and the query counts of the golden frames (output of the C oracle) against oracle/truth.py::shade_frame:
+    an FP64 numpy restatement of raygen, the bounce loop and the closest-hit shader written from the GLSL
+    (REFL raytrace.rgen:40-88, raytrace.rchit:77-155, wavefront.glsl:22-48, raytrace.rmiss:37; BEF raytrace.rgen:22-57) on top
+    of the companion-matrix first-hit solver — no arithmetic shared with the C oracle or the kernels.  The closed-form
+    circle families pin t and N; this pins the control flow (who bounces, who casts a shadow ray, where the loop ends) and
+    the Phong chain.  Pixels whose path has a query that flips under a 1e-4 perturbation are excluded from the colour
+    comparison (<= 3 % of a frame); the counts are compared on the whole frame."""
+    from oracle import truth
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    W = H = 64
+    pc = camera.baseline_push(5)
+    if name == "render_pinhole_mirror":
+        sc, g = camera.single_torus_scene(), camera.baseline_camera(W, H)
+    elif name == "render_pinhole_nested_f64":
+        sc, g = camera.nested_tori_scene(), camera.baseline_camera(W, H)
+    else:
+        sc = camera.single_torus_scene(center=(0.0, 0.0, 0.0), R=6.0, r=1.5, material=camera.PLASTIC)
+        g = camera.toroidal_camera(W, H)
+        pc.rho = 4.0
+    mats = [dict(ambient=tuple(m.ambient), diffuse=tuple(m.diffuse), specular=tuple(m.specular), shininess=m.shininess, illum=m.illum)
+            for m in sc._mats]
+    push = dict(clearColor=pc.clearColor[:], lightPosition=pc.lightPosition[:], lightIntensity=pc.lightIntensity,
+                lightType=pc.lightType, maxDepth=pc.maxDepth, rho=pc.rho)
+    mat4 = lambda a: np.array(a[:], np.float64).reshape(4, 4).T   # column-major storage -> M[row, col]
+    rgba, robust, q = truth.shade_frame(sc.tori_list(), mats, mat4(g.viewInverse), mat4(g.projInverse), g.center[:], push, W, H, cam)
+    assert robust.mean() > 0.95
+    want = z["rgba"].astype(np.float64)
+    rel = (np.abs(rgba - want) / (np.abs(want) + 1e-5)).max(axis=-1)[robust]
+    assert (rel <= 1e-4).mean() >= 0.999 and rel.max() <= 5e-4, (rel.max(), (rel > 1e-4).sum())
+    # counts: every closest-hit query tests every torus; a shadow query tests at least one and at most all of them.
+    # (a non-robust pixel may legitimately take another path: it can shift a count by at most maxDepth queries)
+    n_t, slack = sc.n_tori, int((~robust).sum()) * pc.maxDepth
+    primary, bounce, shadow = (int(v) for v in z["stats"])
+    assert primary == q["primary"] * n_t == W * H * n_t
+    assert abs(bounce - q["bounce"] * n_t) <= slack * n_t
+    assert q["shadow"] - slack <= shadow <= (q["shadow"] + slack) * n_t
