@@ -490,7 +490,6 @@ extern "C" int trt_trace_dev(trt_ctx* ctx, const trt_rays* in, const trt_scene* 
   a.tmin  = tmin;
   a.tmax  = tmax;
   a.stats = nullptr;
-  a.wait_thresh = ctx->tn.trace_variant > 0 ? (uint32_t)ctx->tn.trace_variant : 1u;
   if(ctx->stats_on)
   {
     TRT_HIP(ctx, launch_zero_words((unsigned int*)ctx->d_stats, 16, st));

@@ -585,7 +585,7 @@ constexpr int kRenderWalk = kWalkNested;
 template <class Real, bool DK = false, int WALK = kRenderWalk>
 __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real dx_, Real dy_,
                                                 Real dz_, Real dd, Real inv_dd, Real tmin, Real tmax,
-                                                const TorusK<Real>& T, Real& t_out, WorkCount& wc, int alt = 1, uint32_t wait_thresh = 1u)
+                                                const TorusK<Real>& T, Real& t_out, WorkCount& wc, int alt = 1)
 {
   TorusTest<Real> q;
   ++wc.traced;
@@ -605,32 +605,16 @@ __device__ __forceinline__ bool torus_first_hit(Real ox, Real oy, Real oz, Real 
       // every field the transitions read is a known constant, so the compiler folds step())
       ++wc.evals;
       bool run = q.step();
-      if(wait_thresh <= 1u)
+      // (Letting the lanes at a piece end WAIT while others iterate — so that more trips are the cheap iterate-only ones —
+      // was measured: bit-identical, and slower whatever the threshold: aimed rays 0.085 → 0.107 / 0.126 / 0.147 ms with 8 /
+      // 16 / 32 waiting lanes, profiles/r03_trace_wait.txt.  Idle lanes cost more than the cheaper trips bring.)
+      while(run)
       {
-        while(run)
-        {
-          ++wc.evals;
-          if(__any(!q.iterating()))
-            run = q.step();
-          else
-            run = q.step_iter();
-        }
-      }
-      else
-      {
-        // Lanes at a piece end WAIT while at least one lane iterates and fewer than wait_thresh lanes wait: the trips in
-        // between are the cheap iterate-only ones (48 + 20 instructions against 95 + 75).  A lane's own sequence of
-        // evaluations — and so its root — does not depend on when its trips happen.
-        while(__any(run))
-        {
-          const bool it = run && q.iterating();
-          const uint32_t n_it = (uint32_t)__popcll(__ballot(it)), n_wait = (uint32_t)__popcll(__ballot(run && !it));
-          if(n_it == 0u || n_wait >= wait_thresh)
-          {
-            if(run) { ++wc.evals; run = q.step(); }
-          }
-          else if(it) { ++wc.evals; run = q.step_iter(); }
-        }
+        ++wc.evals;
+        if(__any(!q.iterating()))
+          run = q.step();
+        else
+          run = q.step_iter();
       }
     }
     else
@@ -675,11 +659,11 @@ __device__ __forceinline__ bool round_t(double t, float tmin, float tmax, float&
 
 // One ray against torus i over the open interval (tmin, tmax); t rounded to FP32.
 template <class Real, bool DK = false, int WALK = kRenderWalk>
-__device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t, WorkCount& wc, uint32_t wait_thresh = 1u)
+__device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Real>& r, float tmin, float tmax, float& t, WorkCount& wc)
 {
   Real tt;
   if(!torus_first_hit<Real, DK, WALK>((Real)r.ox, (Real)r.oy, (Real)r.oz, (Real)r.dx, (Real)r.dy, (Real)r.dz, r.dd, r.inv_dd, (Real)r.tmin, (Real)tmax,
-                                torus_k<Real>(S, i), tt, wc, S.dk, wait_thresh))
+                                torus_k<Real>(S, i), tt, wc, S.dk))
     return false;
   return round_t(tt, tmin, tmax, t);
 }
@@ -691,7 +675,7 @@ __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Rea
 // Returns the torus index or -1; `tests` counts ray–torus tests.
 template <class Real, bool DK = false, int WALK = kRenderWalk>
 __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
-                                           float& t_out, uint32_t& tests, WorkCount& wc, uint32_t wait_thresh = 1u)
+                                           float& t_out, uint32_t& tests, WorkCount& wc)
 {
   RayK<Real> r;
   r.set(o, d, tmin, tmax);
@@ -702,7 +686,7 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
     const int i = S.order[k];
     float t;
     ++tests;
-    if(torus_hit<Real, DK, WALK>(S, i, r, tmin, min_(tmax, best), t, wc, wait_thresh))
+    if(torus_hit<Real, DK, WALK>(S, i, r, tmin, min_(tmax, best), t, wc))
     {
       best = t;
       id   = i;

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneK scene, const Tr
     const v3 o = {a.rays.ox[i], a.rays.oy[i], a.rays.oz[i]};
     const v3 d = {a.rays.dx[i], a.rays.dy[i], a.rays.dz[i]};
     float     t;
-    const int id = closest_hit<Real, DK, kWalkTable>(S, o, d, a.tmin, a.tmax, t, tests, wc, a.wait_thresh);   // incoherent rays: trt_device.hpp
+    const int id = closest_hit<Real, DK, kWalkTable>(S, o, d, a.tmin, a.tmax, t, tests, wc);   // incoherent rays: trt_device.hpp
     v3 P = {0.0f, 0.0f, 0.0f}, N = {0.0f, 0.0f, 0.0f};
     if(id >= 0)
     {

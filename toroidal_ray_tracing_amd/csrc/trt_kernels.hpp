@@ -88,7 +88,6 @@ struct TraceArgs {
   trt_hits hits;
   float    tmin, tmax;
   unsigned long long* stats;
-  uint32_t wait_thresh;   // walk of incoherent rays: lanes at a piece end wait until this many do (1 = never wait); trt_device.hpp
 };
 
 enum RenderVariant { kRenderStatic = 0, kRenderPersistent = 1, kRenderListed = 2 };
