@@ -686,7 +686,11 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
     const int i = S.order[k];
     float t;
     ++tests;
+#ifdef TRT_FULL_WINDOW   // timing experiment only (the tail of config 4): every torus over the FULL interval, minimum afterwards
+    if(torus_hit<Real, DK, WALK>(S, i, r, tmin, tmax, t, wc) && t < best)
+#else
     if(torus_hit<Real, DK, WALK>(S, i, r, tmin, min_(tmax, best), t, wc))
+#endif
     {
       best = t;
       id   = i;
