@@ -236,8 +236,10 @@ int trt_render_tiled_dev(trt_ctx* ctx, const trt_globals* g, const trt_push* pc,
  * n_frames calls of trt_render_tiled_dev / trt_render_dev, bit for bit.
  * Restrictions (TRT_E_INVALID otherwise; render such frames one by one): the listed render variant and the default
  * root solver (TRT_SOLVE_F32 / _F64); no RenderedData export; W <= 65528; 1 <= n_frames <= TRT_MAX_BATCH; with the
- * toroidal camera all frames must share eye and centre (they may differ in rho: the rho sweep of
- * BEF/main.cpp:236-258), because the ctx holds one set of trigonometry tables.  tiling may be NULL (whole frames). */
+ * toroidal camera all frames must have the same trigonometry tables, because the ctx holds one set: the same eye and
+ * centre — and, when the eye is above or below the centre (BEF rgen:45-53: theta then depends on rho), the same rho; with
+ * the eye at the centre's height the frames may differ in rho (the rho sweep of BEF/main.cpp:236-258).
+ * tiling may be NULL (whole frames). */
 typedef struct trt_frame {
   const trt_globals* g;
   const trt_push*    pc;

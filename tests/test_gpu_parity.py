@@ -1257,6 +1257,22 @@ def test_splat_bit_exact(tr, oracle):
         torch.cuda.synchronize()
         want = oracle.splat(pts, vp, W, H, point_size=size)
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=f"point_size {size}")
+    # larger images take the other scatter kernels: up to 2,048 bins (LDS-sorted, the wider instantiation) and beyond (direct);
+    # big points on the small image above make a chunk's records overflow the LDS staging area
+    for W2, H2, n2 in [(4096, 2048, 120_000), (8192, 4100, 120_000)]:
+        pts2 = np.zeros((n2, 8), np.float32)
+        pts2[:, :3] = rng.uniform(-3, 3, (n2, 3))
+        pts2[:, 4:7] = rng.uniform(0, 1, (n2, 3))
+        pts2[n2 // 2:n2 // 2 + 2000] = pts2[:2000]
+        vp2 = camera.perspective_vk(70, W2 / H2) @ camera.look_at((0.5, 1.0, 5.0), (0, 0, 0))
+        d2 = torch.from_numpy(pts2).to(dev)
+        out2 = torch.empty(H2, W2, 4, device=dev)
+        for size in (2.5, 20.0):
+            tr.splat_dev(d2.data_ptr(), n2, vp2, W2, H2, out2.data_ptr(), point_size=size, stream=s)
+            torch.cuda.synchronize()
+            want = oracle.splat(pts2, vp2, W2, H2, point_size=size)
+            np.testing.assert_array_equal(out2.cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=f"{W2}x{H2} point_size {size}")
+        del d2, out2
     # no points at all: the clear colour everywhere
     tr.splat_dev(0, 0, vp, W, H, out.data_ptr(), clear=(0.1, 0.2, 0.3, 1.0), stream=s)
     torch.cuda.synchronize()

@@ -19,6 +19,8 @@ rng = np.random.default_rng(seed)
 bad, t0 = 0, time.time()
 for k in range(n_rounds):
     W, H = int(rng.integers(8, 700)), int(rng.integers(8, 500))
+    if k % 10 == 9:   # the other scatter kernels: up to 512 bins / up to 2,048 bins (both LDS-sorted) / more (direct)
+        W, H = [(2500, 1400), (4096, 2048), (3000, 4000), (8192, 4100)][(k // 10) % 4]
     n = int(rng.choice([0, 1, 63, 1000, 40_000, 250_000]))
     pts = np.zeros((n, 8), np.float32)
     ext = float(rng.uniform(0.5, 6.0))

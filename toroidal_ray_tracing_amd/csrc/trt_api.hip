@@ -277,7 +277,7 @@ int build_toro(trt_ctx* ctx, const trt_globals& g, const trt_push& pc, uint32_t 
   const bool same = key.valid && key.W == W && key.H == H && !std::memcmp(&key.omega, &omega, 4)
                     && !std::memcmp(&key.theta, &theta, 4);
   if(!same && must_match)
-    return fail(ctx, TRT_E_INVALID, "trt_render_batch: the frames of a batch must share the toroidal camera's eye and centre (the ctx holds "
+    return fail(ctx, TRT_E_INVALID, "trt_render_batch: the frames of a batch must share the toroidal camera's trigonometry tables (same eye, centre and — with the eye off the centre's height — rho; the ctx holds "
                 "one set of trigonometry tables); render these frames one by one");
   if(!same && capturing(stream))
     return fail(ctx, TRT_E_INVALID, "toroidal camera: the trigonometry tables of this (W, H, centre, rho) frame are not on the "
