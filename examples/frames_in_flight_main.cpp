@@ -6,7 +6,12 @@
 // (a few heavy tiles on an otherwise idle chip — DESIGN.md §5) run beside the body of the next.  Eight nested tori,
 // 4096², FP64 solve: 0.31 ms per frame with one context, 0.26 ms with two.
 //
-// Usage: frames_in_flight [K=2] [frames=64] [size=4096] [nested=1] [f64=1]
+// The second half is the other way to keep frames in flight, the one a rank of a multi-GPU job uses: trt_render_batch_dev renders
+// `parts` consecutive frames' 1/parts part of the image (trt_tiling) with ONE pair of launches on ONE stream — as much work as a
+// full frame, where a single part does not fill the chip (a 1/8 part of the 4096² single-torus frame: 41 µs per frame one by
+// one, 14.5 µs eight per launch) — and checks the batch against the same frames rendered one by one, bit for bit.
+//
+// Usage: frames_in_flight [K=2] [frames=64] [size=4096] [nested=1] [f64=1] [parts=8]
 // Prints the time per frame for 1 … K frames in flight and checks that every context produced the same image.
 #include <hip/hip_runtime.h>
 
@@ -45,6 +50,7 @@ int main(int argc, char** argv)
   const int      K = argc > 1 ? atoi(argv[1]) : 2, frames = argc > 2 ? atoi(argv[2]) : 64;
   const uint32_t W = argc > 3 ? atoi(argv[3]) : 4096, H = W;
   const bool     nested = argc > 4 ? atoi(argv[4]) != 0 : true, f64 = argc > 5 ? atoi(argv[5]) != 0 : true;
+  const uint32_t parts = argc > 6 ? (uint32_t)atoi(argv[6]) : 8u;
   if(K < 1 || K > 8 || frames < 1) { std::fprintf(stderr, "K in 1..8, frames >= 1\n"); return 1; }
 
   // scene: BASELINE config 4 (eight nested tori, the outer shells mirrors) or config 3 (one mirror torus)
@@ -138,6 +144,49 @@ int main(int argc, char** argv)
   std::printf("images of the %d contexts %s; centre pixel = %g %g %g %g\n", K, rc ? "DIFFER" : "identical",
               a[((size_t)(H / 2) * W + W / 2) * 4], a[((size_t)(H / 2) * W + W / 2) * 4 + 1], a[((size_t)(H / 2) * W + W / 2) * 4 + 2],
               a[((size_t)(H / 2) * W + W / 2) * 4 + 3]);
+  // ---- a batch of frames per launch: what one rank of a `parts`-GPU job renders (part 0 of the interleaved row tiling) ----
+  if(parts >= 2 && parts <= TRT_MAX_BATCH && H % (parts * 8) == 0)
+  {
+    uint32_t group = H / (parts * 16);              // 16 interleaved groups per rank, whole 8-row tile bands
+    if(group < 8 || group % 8) group = 8;
+    const trt_tiling til{group, parts, 0, 1};
+    const uint32_t rows = trt_tiling_rows(&til, H);
+    const size_t   pbytes = (size_t)rows * W * 4 * sizeof(float);
+    std::vector<float*>    out(2 * parts, nullptr);   // [0, parts): the batch's output sets; [parts, 2 parts): one by one
+    std::vector<trt_push>  pcs(parts, pc);
+    std::vector<trt_frame> fr(parts);
+    for(uint32_t i = 0; i < 2 * parts; ++i) CK(hipMalloc((void**)&out[i], pbytes));
+    for(uint32_t i = 0; i < parts; ++i)
+    {
+      pcs[i].maxDepth = 1 + int(i % 5);             // the frames differ (a real loop moves the camera: g is per frame too)
+      fr[i] = trt_frame{&g, &pcs[i], out[i], nullptr};
+    }
+    for(int r = 0; r < 3; ++r) TK(ctx[0], trt_render_batch_dev(ctx[0], fr.data(), parts, &scene, W, H, &til, TRT_CAMERA_PINHOLE, stream[0]));
+    for(uint32_t i = 0; i < parts; ++i)
+      TK(ctx[0], trt_render_tiled_dev(ctx[0], &g, &pcs[i], &scene, W, H, &til, TRT_CAMERA_PINHOLE, out[parts + i], nullptr, nullptr, stream[0]));
+    CK(hipDeviceSynchronize());
+    std::vector<float> x((size_t)rows * W * 4), y(x.size());
+    for(uint32_t i = 0; i < parts; ++i)
+    {
+      CK(hipMemcpy(x.data(), out[i], pbytes, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(y.data(), out[parts + i], pbytes, hipMemcpyDeviceToHost));
+      if(std::memcmp(x.data(), y.data(), pbytes) != 0) { std::printf("batch frame %u DIFFERS from the frame rendered alone\n", i); rc = 1; }
+    }
+    const int reps = frames / (int)parts > 0 ? frames / (int)parts : 1;
+    auto t0 = std::chrono::steady_clock::now();
+    for(int r = 0; r < reps; ++r)
+      for(uint32_t i = 0; i < parts; ++i)
+        TK(ctx[0], trt_render_tiled_dev(ctx[0], &g, &pcs[i], &scene, W, H, &til, TRT_CAMERA_PINHOLE, out[parts + i], nullptr, nullptr, stream[0]));
+    CK(hipDeviceSynchronize());
+    const double one = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps * parts);
+    t0 = std::chrono::steady_clock::now();
+    for(int r = 0; r < reps; ++r) TK(ctx[0], trt_render_batch_dev(ctx[0], fr.data(), parts, &scene, W, H, &til, TRT_CAMERA_PINHOLE, stream[0]));
+    CK(hipDeviceSynchronize());
+    const double bat = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps * parts);
+    std::printf("1/%u part of the frame (%u rows in groups of %u): %.1f us per frame one by one, %.1f us per frame %u per launch; batch %s\n", parts, rows,
+                group, one, bat, parts, rc ? "DIFFERS" : "identical to the frames rendered alone");
+    for(float* q : out) (void)hipFree(q);
+  }
   for(int k = 0; k < K; ++k)
   {
     trt_destroy(ctx[k]);
