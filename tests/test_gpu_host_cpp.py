@@ -111,9 +111,9 @@ def test_frames_in_flight_example():
     p = subprocess.run([exe, "3", "9", "320", "1", "1"], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "images of the 3 contexts identical" in p.stdout and p.stdout.count("in flight:") == 3
-    # … and trt_render_batch_dev: the 1/4 part of 4 consecutive frames (maxDepth 1..4) in one pair of launches, compared by the
-    # program with the same frames rendered one by one (size 320 = 4 parts x 10 groups of 8 rows)
-    assert "4 per launch; batch identical to the frames rendered alone" not in p.stdout   # (320 is no multiple of 8 parts x 8 rows)
+    # … and trt_render_batch_dev: the 1/8 (above) and the 1/4 part of consecutive frames (maxDepth 1, 2, …) in one pair of
+    # launches each, compared by the program with the same frames rendered one by one
+    assert "8 per launch; batch identical to the frames rendered alone" in p.stdout
     p = subprocess.run([exe, "1", "8", "320", "1", "1", "4"], capture_output=True, text=True)
     assert p.returncode == 0 and "4 per launch; batch identical to the frames rendered alone" in p.stdout, p.stdout + p.stderr
     p = subprocess.run([exe, "2", "4", "200", "0", "0"], capture_output=True, text=True)    # one torus, FP32
