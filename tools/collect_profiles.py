@@ -17,12 +17,14 @@ def one(pattern):
 
 
 stats = one("trace/*/*kernel_stats.csv")
-if stats:
-    # this library's kernels only (bench.py's secondary configurations build their inputs with torch kernels)
-    lines = open(stats).read().splitlines()
-    keep = [lines[0]] + [ln for ln in lines[1:] if "trt::" in ln.split(",")[0]]
-    open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w").write("\n".join(keep) + "\n")
-for name in ("bench.json", "bench_under_rocprof.json"):
+for pattern, suffix in (("trace/*/*kernel_stats.csv", "kernel_stats.csv"), ("trace1/*/*kernel_stats.csv", "kernel_stats_one_output_set.csv")):
+    f = one(pattern)
+    if f:
+        # this library's kernels only (bench.py's secondary configurations build their inputs with torch kernels)
+        lines = open(f).read().splitlines()
+        keep = [lines[0]] + [ln for ln in lines[1:] if "trt::" in ln.split(",")[0]]
+        open(os.path.join(dst, f"{rnd}_{suffix}"), "w").write("\n".join(keep) + "\n")
+for name in ("bench.json", "bench_under_rocprof.json", "bench_under_rocprof_one_set.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
 
@@ -45,10 +47,10 @@ fetch = write = 0.0
 # (with / without query counters): take the one the timed steps use (most launches)
 # the headline frame = tile_classify_kernel + the plain FP32 instantiation of the variant's render kernel (the PMC passes
 # also run bench.py's secondary configurations: FP64, RenderedData, persistent … — not part of the headline traffic)
-want = {"listed": "render_listed_kernel<float, false, false, false, false>", "persistent": "render_persistent_kernel<float>",
+want = {"listed": "render_listed_kernel<float, false, false, false, false, false>", "persistent": "render_persistent_kernel<float>",
         "static": "render_static_kernel<float, 8, false>"}[variant]
 for k, d in summary.items():
-    if want in k or k.endswith("tile_classify_kernel<false>"):
+    if want in k or k.endswith("tile_classify_kernel<false, false>"):
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md §HBM: FETCH_SIZE
         # tallies 128-B read requests at 64 B, so wide coalesced reads count HALF -> doubled here;
         # WRITE_SIZE is exact for 16-B-per-lane streaming stores (this kernel's dominant stores).
@@ -59,7 +61,8 @@ if os.path.exists(shafile):
     traffic["kernel_sources_sha256"] = open(shafile).read().strip()
 traffic["size"], traffic["depth"] = 4096, 5   # the workload of the passes (bench.py defaults); bench.py ignores the file for any other
 traffic[variant] = {"hbm_bytes_per_launch": fetch + write, "write_bytes": write, "fetch_bytes_corrected": fetch,
-                    "note": "classify + render kernels of one frame; FETCH_SIZE doubled per the gfx950 correction"}
+                    "note": "classify + render kernels of one frame, frames rotating over four output sets (bench.py --output-sets 4); "
+                            "FETCH_SIZE doubled per the gfx950 correction"}
 json.dump(traffic, open(os.path.join(dst, f"traffic_{rnd}.json"), "w"), indent=1)
 print("\n".join(ln[:160] for ln in open(os.path.join(dst, f"{rnd}_kernel_stats.csv")).read().splitlines()) if stats else "no kernel stats")
 print(json.dumps(traffic, indent=1))

@@ -5,7 +5,7 @@
 set -u
 P=${1:-8}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/tiled_part; mkdir -p $OUT; rm -f $OUT/report.json
-python3 $R/tools/bench_tiled_streams.py --parts $P --streams 1 2 3 4 --both 2>&1 | grep -v amdgpu.ids | tee $OUT/wall.log
+python3 $R/tools/bench_tiled_streams.py --parts $P --streams 1 2 3 4 --batch 2 4 $P --both 2>&1 | grep -v amdgpu.ids | tee $OUT/wall.log
 cd /tmp && export TMPDIR=/tmp
 for MODE in eager graph; do
   for K in 1 2 4; do
@@ -18,3 +18,10 @@ for MODE in eager graph; do
     rm -rf $OUT/trace_${MODE}_$K
   done
 done
+# $P frames per launch on one stream (trt_render_batch_dev)
+rm -rf $OUT/trace_batch
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_batch -- python3 $R/tools/bench_tiled_streams.py --parts $P --streams --batch $P > $OUT/run_batch.log 2>&1 || tail -3 $OUT/run_batch.log
+T=$(ls $OUT/trace_batch/*/*kernel_trace.csv | head -1)
+python3 $R/tools/tiled_trace_report.py $T --min-frames 16 --frames-per-kernel $P --label "${P} parts, part 0, 1 stream, $P frames per launch, eager (under rocprofv3 --kernel-trace)" --json $OUT/report.json
+grep "us per frame" $OUT/run_batch.log
+rm -rf $OUT/trace_batch

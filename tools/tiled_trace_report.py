@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("trace")
 ap.add_argument("--gap-us", type=float, default=300.0)
 ap.add_argument("--min-frames", type=int, default=64)
+ap.add_argument("--frames-per-kernel", type=int, default=1, help="frames one render launch covers (trt_render_batch_dev)")
 ap.add_argument("--label", default="")
 ap.add_argument("--json", default="")
 a = ap.parse_args()
@@ -32,7 +33,7 @@ if cur:
     batches.append(cur)
 res = []
 for b in batches:
-    frames = sum(1 for x in b if x[2] == "render")
+    frames = sum(1 for x in b if x[2] == "render") * a.frames_per_kernel
     if frames < a.min_frames:
         continue
     span = max(x[1] for x in b) - b[0][0]
