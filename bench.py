@@ -93,8 +93,9 @@ def parse():
     ap.add_argument("--gather", default="fp32", choices=["fp32", "rgba8", "none"],
                     help="N>1: what is all-gathered (default: the rgba32f framebuffer)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="frames in flight per rank, each on its own HIP stream with its own context and output set "
-                         "(default 1; round 2 used 4 for N > 1 — superseded by --batch, with which it cannot be combined)")
+                    help="HIP streams per rank, each with its own context; frames (or, with --batch, launches of B frames) take them "
+                         "in turn.  Default: 2 for N > 1 — the classification of one launch runs beside the render kernel of the one "
+                         "before (1/8 part: 14.5 -> 13.4-13.9 us per frame, tools/bench_tiled_streams.py) — and 1 for N = 1")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="one GPU: run the N>1 code path (RCCL group of one rank, forced collectives) — a rehearsal, not a measurement")
     ap.add_argument("--gather-every", default="step",
@@ -400,8 +401,9 @@ def dry_run(a, world, rank):
         cuda_stream = 0
     ge = 2 if a.gather_every == "step" else max(1, int(a.gather_every))   # rehearsal: a "step" of two frames
     from toroidal_ray_tracing_amd import abi
-    nb = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 else 1)   # as worker(): N frames per launch
-    frame = trtd.TiledFrame(_PatternTracer(rank), W, H, world, rank, torch.device("cpu"), group_rows=a.group_rows or None,
+    nb = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 else 1)   # as worker(): N frames per launch,
+    ns = a.streams if a.streams > 0 else (2 if world > 1 else 1)                           # the launches alternating over two streams
+    frame = trtd.TiledFrame([_PatternTracer(rank) for _ in range(ns)], W, H, world, rank, torch.device("cpu"), group_rows=a.group_rows or None,
                             gather=a.gather if a.gather != "rgba8" else "fp32", gather_every=ge, batch=nb)
     ok = True
     if world > 1:
@@ -468,10 +470,12 @@ def worker(a, world, rank, local):
     pc = camera.baseline_push(a.depth)
     gather_every = F if a.gather_every == "step" else max(1, int(a.gather_every))
     # A 1/N part of the frame does not fill the chip: N > 1 renders N consecutive frames' parts per launch (a batch: the work
-    # of one full frame), on ONE stream.  (Round 2 kept 4 frames in flight on 4 streams instead — `--streams 4 --batch 1`:
-    # 17-25 µs per 1/8 part depending on how the runtime maps the streams to hardware queues, against 14-15 µs batched.)
-    n_streams = a.streams if a.streams > 0 else 1
-    n_batch = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 and n_streams == 1 else 1)
+    # of one full frame), the launches alternating over TWO streams so that the classification kernel of one batch (≈10 µs,
+    # latency-bound) runs beside the render kernel of the batch before.  (Round 2 kept 4 single frames in flight on 4 streams
+    # instead — `--streams 4 --batch 1`: 17-25 µs per 1/8 part depending on how the runtime maps the streams to hardware
+    # queues; batched on one stream 14.5 µs, on two 13.4-13.9 µs = the full frame's 107.9 µs / 8: profiles/r03_tiled_part.json.)
+    n_streams = a.streams if a.streams > 0 else (2 if world > 1 else 1)
+    n_batch = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 else 1)
     trs = [Tracer(local) for _ in range(n_streams)]
     tr = trs[0]
     if a.variant:
@@ -677,8 +681,9 @@ def worker(a, world, rank, local):
             "value_gather_every_frame": other,
             "step_launch": ("one hipGraph replay per step" if graphed else "eager launches"),
             "rehearse_collective": bool(a.rehearse_collective),
-            "frames_in_flight": n_streams,
+            "streams": n_streams,
             "frames_per_launch": n_batch,
+            "frames_in_flight": n_streams * n_batch,
             "output_sets": frame.n_sets,
             # the rank-local renders alone (max over ranks of the HIP-event render time per frame): the part of the path that shards
             "render_only_primary_tests_per_s": cnt["primary_tests"] / (kern_ms_max * 1e-3) if multi else None,

@@ -72,6 +72,10 @@ class _OracleTracer:
             local[k:k + G] = band[y0:y0 + G]
         ctypes.memmove(rgba_ptr, local.ctypes.data, local.nbytes)
 
+    def render_batch_dev(self, scene, frames, W, H, tiling=None, camera=0, stream=0):
+        for g, pc, rgba_ptr, hit_ptrs in frames:
+            self.render_tiled_dev(scene, g, pc, W, H, tiling, rgba_ptr, camera=camera, hit_ptrs=hit_ptrs, stream=stream)
+
     def post_dev(self, rgba_ptr, n_pixels, f32_out_ptr=0, unorm8_out_ptr=0, stream=0):
         import ctypes
         src = np.ctypeslib.as_array(ctypes.cast(rgba_ptr, ctypes.POINTER(ctypes.c_float)), shape=(n_pixels, 4))
@@ -118,11 +122,20 @@ def _worker(rank, world, port, W, H, G, out):
         for depth in (1, 2, 1, 2, 1, 2, 1, 3, 1):
             framek.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
         fullk = framek.finish().clone()
+        # what bench.py --gpus N runs: two frames per launch, the launches alternating over two contexts (four output sets),
+        # a gather every 6th frame: frame 5 is gathered out of set 1 of the THIRD launch (context 0 again), frame 11
+        # (maxDepth 3, set 3, context 1) is handed out; a thirteenth frame stays queued until finish() flushes it
+        frameq = trtd.TiledFrame([tr, _OracleTracer()], W, H, world, rank, torch.device("cpu"), gather_every=6, batch=2)
+        assert "2 frames per launch" in frameq.describe() and "2 streams" in frameq.describe() and len(frameq.locals) == 4
+        for depth in (1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 3, 1):
+            frameq.render(sc, g, camera.baseline_push(depth), abi.TRT_CAMERA_PINHOLE, _Stream())
+        fullq = frameq.finish().clone()
         if rank == 0:
             want, _, _, _ = tr.oracle.render(sc, g, camera.baseline_push(3), W, H, want_hits=False)
             ok = bool(np.array_equal(full.numpy(), want))
             ok = ok and full8.dtype == torch.uint8 and bool(np.array_equal(full8.numpy(), tr.oracle.post(want)[1]))
             ok = ok and bool(np.array_equal(fullb.numpy(), want)) and bool(np.array_equal(fullk.numpy(), want))
+            ok = ok and bool(np.array_equal(fullq.numpy(), want))
             out.put(ok)
         dist.barrier()
     finally:

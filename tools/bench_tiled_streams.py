@@ -20,6 +20,7 @@ ap.add_argument("--streams", type=int, nargs="*", default=[1, 2, 3, 4])
 ap.add_argument("--frames", type=int, default=192, help="frames per batch (a multiple of every --streams value)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--batch", type=int, nargs="*", default=[], help="also: B frames per launch on ONE stream (trt_render_batch_dev)")
+ap.add_argument("--batch-streams", type=int, nargs="*", default=[1], help="... and on K streams, the launches taking them in turn")
 ap.add_argument("--graph", action="store_true", help="replay each batch as one hipGraph")
 ap.add_argument("--both", action="store_true", help="eager and graph, interleaved rounds in one process")
 ap.add_argument("--scene", default="single", choices=["single", "nested"], help="nested: the eight nested tori of config 4")
@@ -32,7 +33,7 @@ g, pc = camera.baseline_camera(W, H), camera.baseline_push(5)
 n = a.parts
 G = trtd.default_group_rows(H, n, trtd.DEFAULT_CYCLES) if n > 1 else None
 cur = torch.cuda.current_stream()
-for K, B in [(k, 1) for k in a.streams] + [(1, b) for b in a.batch]:
+for K, B in [(k, 1) for k in a.streams] + [(k, b) for b in a.batch for k in a.batch_streams]:
     F = a.frames - a.frames % (K * B)
     trs = [Tracer(0) for _ in range(K)]
     if a.f64:

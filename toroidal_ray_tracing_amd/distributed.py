@@ -100,8 +100,9 @@ class TiledFrame:
         of the K streams, so that a set always belongs to one stream) — consecutive frames then never write the same
         buffers and nothing of a frame is still in the 256-MB Infinity Cache when it is written again (bench.py's
         roofline pass).  batch: B > 1 collects B consecutive frames and renders them with ONE pair of launches
-        (trt_render_batch_dev; one tracer / one stream): B parts of a frame are the work of B/N full frames — a launch
-        that fills the chip where a single 1/N part does not.  The output sets are then at least B."""
+        (trt_render_batch_dev): B parts of a frame are the work of B/N full frames — a launch that fills the chip where a
+        single 1/N part does not.  With K tracers the launches take the K streams in turn, so that the classification of
+        one batch runs beside the render kernel of the batch before.  The output sets are then at least K·B."""
         self.trs = list(tracer) if isinstance(tracer, (list, tuple)) else [tracer]
         self.tr = self.trs[0]
         self.W, self.H, self.world, self.rank = W, H, world, rank
@@ -124,14 +125,15 @@ class TiledFrame:
         self.device = torch.device(device)
         K = len(self.trs)
         self.batch = max(1, int(batch))
-        if self.batch > 1 and K != 1:
-            raise ValueError("batch > 1 renders on one stream with one tracer")
         if self.batch > abi.TRT_MAX_BATCH:
             raise ValueError(f"batch={self.batch} > TRT_MAX_BATCH")
         self._queued = []          # batch mode: (g, pc, output set, gather?) of the frames not yet launched
+        self._flushes = 0          # batch mode: launches since the last join() — launch j goes to stream j % K
         f32 = dict(dtype=torch.float32, device=device)
-        # one output set per render stream, or more (output_sets): frame i renders on stream i % K into set i % n_sets
-        self.n_sets = ((max(K, self.batch, int(output_sets)) + K - 1) // K) * K
+        # one output set per frame in flight (K streams x B frames per launch), or more (output_sets): frame i renders into
+        # set i % n_sets on stream (i // B) % K; n_sets is a multiple of K·B, so a set is only ever written on one stream
+        unit = K * self.batch
+        self.n_sets = ((max(unit, int(output_sets)) + unit - 1) // unit) * unit
         self.locals = [torch.empty(self.local_rows, W, 4, **f32) for _ in range(self.n_sets)]
         self.hit_sets = []
         for _ in range(self.n_sets):
@@ -176,7 +178,7 @@ class TiledFrame:
                 if self.gather else "no gather")
         k = f"; {len(self.trs)} frames in flight on {len(self.trs)} streams" if len(self.trs) > 1 else ""
         if self.batch > 1:
-            k = f"; {self.batch} frames per launch (trt_render_batch_dev)"
+            k = f"; {self.batch} frames per launch (trt_render_batch_dev)" + (f", launches alternating over {len(self.trs)} streams" if len(self.trs) > 1 else "")
         return f"{self.world} ranks x {self.local_rows} rows in interleaved groups of {self.group_rows}; {tail}{k}"
 
     def _on(self, stream):
@@ -199,7 +201,7 @@ class TiledFrame:
         frame is stable)."""
         K = len(self.trs)
         k = self._k % K
-        o = self._k % self.n_sets   # output set; n_sets is a multiple of K, so set o is only ever written on stream k
+        o = self._k % self.n_sets   # output set; n_sets is a multiple of K (K·B in batch mode), so set o is only ever written on one stream
         self._k += 1
         self._caller = stream
         if self.batch > 1:
@@ -241,12 +243,22 @@ class TiledFrame:
         if not self._queued:
             return
         q, self._queued = self._queued, []
+        kb = self._flushes % len(self.trs)   # (full batches between two join()s: n_sets / B is a multiple of K, a set keeps its stream)
+        self._flushes += 1
+        tr = self.trs[kb]
+        if self._own is not None:
+            if not self._forked:
+                if self.device.type == "cuda":
+                    for s in self._own:
+                        s.wait_stream(stream)
+                self._forked = True
+            stream = self._own[kb]
         frames = [(g, pc, self.locals[o].data_ptr(), {n: v.data_ptr() for n, v in self.hit_sets[o].items()}) for g, pc, o, _ in q]
-        self.tr.render_batch_dev(self._scene, frames, self.W, self.H, self.tiling if self.world > 1 else None, camera=self._camera,
-                                 stream=stream.cuda_stream)
+        tr.render_batch_dev(self._scene, frames, self.W, self.H, self.tiling if self.world > 1 else None, camera=self._camera,
+                            stream=stream.cuda_stream)
         for _, _, o, do_gather in q:
             if do_gather:
-                self._gather(o, stream, self.tr)
+                self._gather(o, stream, tr)
 
     def _gather(self, o, s, tr):
         """Copy or tonemap output set o into a staging buffer on stream s and start the all-gathers behind that."""
@@ -311,6 +323,7 @@ class TiledFrame:
                 for s in self._own:
                     side.wait_stream(s)
         stream.wait_stream(side)
+        self._forked, self._flushes = False, 0   # (the capture forked and joined the own streams itself)
         self._graph, self._graph_frames = graph, n_frames
         return graph
 
@@ -323,7 +336,7 @@ class TiledFrame:
         self._k += n
         o = (self._k - 1) % self.n_sets
         if self.gather and self._k % self.gather_every == 0:
-            self._gather(o, stream, self.trs[(n - 1) % len(self.trs)])
+            self._gather(o, stream, self.trs[((n - 1) // self.batch) % len(self.trs)])
         if not self.gather:
             self._last = o
 
@@ -333,6 +346,7 @@ class TiledFrame:
         stream = stream or self._caller
         if self.batch > 1 and stream is not None:
             self.flush(stream)
+        self._flushes = 0
         if self._own is not None and self._forked and stream is not None:
             if self.device.type == "cuda":
                 for s in self._own:
