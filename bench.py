@@ -94,8 +94,9 @@ def parse():
                     help="N>1: what is all-gathered (default: the rgba32f framebuffer)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams per rank, each with its own context; frames (or, with --batch, launches of B frames) take them "
-                         "in turn.  Default: 2 for N > 1 — the classification of one launch runs beside the render kernel of the one "
-                         "before (1/8 part: 14.5 -> 13.4-13.9 us per frame, tools/bench_tiled_streams.py) — and 1 for N = 1")
+                         "in turn.  Default 1.  Two streams let the classification of one launch run beside the render kernel of "
+                         "the one before: 1/8 part 14.5 -> 13.4-13.9 us per frame on a box in the chip's fast state, 14.2 -> 15.1 us "
+                         "on one in its slow state (profiles/r03_ab_batch_streams.txt) — no default can be built on that")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="one GPU: run the N>1 code path (RCCL group of one rank, forced collectives) — a rehearsal, not a measurement")
     ap.add_argument("--gather-every", default="step",
@@ -402,7 +403,7 @@ def dry_run(a, world, rank):
     ge = 2 if a.gather_every == "step" else max(1, int(a.gather_every))   # rehearsal: a "step" of two frames
     from toroidal_ray_tracing_amd import abi
     nb = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 else 1)   # as worker(): N frames per launch,
-    ns = a.streams if a.streams > 0 else (2 if world > 1 else 1)                           # the launches alternating over two streams
+    ns = a.streams if a.streams > 0 else 1
     frame = trtd.TiledFrame([_PatternTracer(rank) for _ in range(ns)], W, H, world, rank, torch.device("cpu"), group_rows=a.group_rows or None,
                             gather=a.gather if a.gather != "rgba8" else "fp32", gather_every=ge, batch=nb)
     ok = True
@@ -470,11 +471,12 @@ def worker(a, world, rank, local):
     pc = camera.baseline_push(a.depth)
     gather_every = F if a.gather_every == "step" else max(1, int(a.gather_every))
     # A 1/N part of the frame does not fill the chip: N > 1 renders N consecutive frames' parts per launch (a batch: the work
-    # of one full frame), the launches alternating over TWO streams so that the classification kernel of one batch (≈10 µs,
-    # latency-bound) runs beside the render kernel of the batch before.  (Round 2 kept 4 single frames in flight on 4 streams
-    # instead — `--streams 4 --batch 1`: 17-25 µs per 1/8 part depending on how the runtime maps the streams to hardware
-    # queues; batched on one stream 14.5 µs, on two 13.4-13.9 µs = the full frame's 107.9 µs / 8: profiles/r03_tiled_part.json.)
-    n_streams = a.streams if a.streams > 0 else (2 if world > 1 else 1)
+    # of one full frame) on ONE stream: 14.2-14.5 µs per 1/8 part against 13.5-14.8 µs for the full frame / 8 on the same box
+    # (profiles/r03_ab_batch_streams.txt, r03_tiled_part.json).  (Round 2 kept 4 single frames in flight on 4 streams instead —
+    # `--streams 4 --batch 1`: 17-25 µs per 1/8 part depending on how the runtime maps the streams to hardware queues.
+    # `--streams 2` with batches lets a batch's classification run beside the previous batch's render kernel: a gain on a
+    # box in the chip's fast state, a loss on one in its slow state — not the default.)
+    n_streams = a.streams if a.streams > 0 else 1
     n_batch = a.batch if a.batch > 0 else (min(world, abi.TRT_MAX_BATCH) if world > 1 else 1)
     trs = [Tracer(local) for _ in range(n_streams)]
     tr = trs[0]
