@@ -63,12 +63,20 @@ def lib():
         L.oracle_splat.argtypes = [C.c_void_p, C.c_uint64, abi.f32p, C.c_uint32, C.c_uint32, abi.f32p, C.c_float,
                                    C.c_void_p]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_set_enclosure_cull.restype = None
+        L.oracle_set_enclosure_cull.argtypes = [C.c_int]
         _lib = L
     return _lib
 
 
 def max_threads():
     return int(lib().oracle_max_threads())
+
+
+def set_enclosure_cull(on):
+    """Tests only: 0 makes every query test every torus (the semantics before the enclosure cull of T3, trt_oracle.c);
+    1 (the default, what the library implements) skips the tori whose tube lies inside a tube the ray starts outside of."""
+    lib().oracle_set_enclosure_cull(1 if on else 0)
 
 
 def _check(rc, what):

@@ -112,7 +112,24 @@ typedef struct {
   int          f64;
   int          dk;   /* 0: Fourier–Newton walk; alternative root solvers: 1 Durand–Kerner, 2 Ferrari */
   int          order[TRT_MAX_TORI]; /* test order: descending bounding radius R + r, ties by index */
+  uint32_t     inside[TRT_MAX_TORI]; /* enclosure masks (T3, below): bit k = the torus at test-order position k */
 } scene_t;
+
+/* Enclosure cull (build-defined, like the rest of T3).  A ray whose origin lies OUTSIDE the tube of torus j
+ * must cross j's surface before it can reach a tube that lies strictly inside j's: the closest hit is never the inner
+ * torus, and an inner torus shadows nothing that j does not.  The queries therefore skip the tori named by a mask:
+ *   - inside[j]: the tori whose tube lies strictly inside tube j (same axis line; centre circles everywhere
+ *     sqrt(dR² + dy²) apart; that distance + r_k < r_j with 2^-10 of r_j to spare);
+ *   - primary rays: the union of inside[j] over the tori j whose tube every ray origin of the frame lies outside of
+ *     (the eye, or the circle of radius rho around it for the toroidal camera), with the same margin;
+ *   - a hit on torus h that the path leaves OUTWARDS adds inside[h]: always for the shadow ray (it is cast only when
+ *     N·L > 0), for the reflected ray when the incoming ray met the surface from outside (N·D < 0); the mask of a path
+ *     only grows (a segment that ends on a surface has crossed none, so what the origin was outside of, the hit point is).
+ * A skipped torus still counts as a test of the query.  g_enclosure_cull = 0 (oracle_set_enclosure_cull, tests only)
+ * tests every torus in every query: the images, records and query counts must come out the same — and do, on every
+ * fixture and fuzz scene (tests/test_oracle.py::test_enclosure_cull_changes_nothing). */
+static int g_enclosure_cull = 1;
+void oracle_set_enclosure_cull(int on) { g_enclosure_cull = on; }
 
 static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
 {
@@ -148,20 +165,52 @@ static int scene_prepare(const trt_scene* s, int precision, scene_t* out)
     }
     out->order[k] = i;
   }
+  /* enclosure masks: plain double arithmetic on the scene's floats, as trt_api.hip build_scene_uncached */
+  for(int j = 0; j < out->n; ++j)
+  {
+    const trt_torus* J = &s->tori[j];
+    out->inside[j] = 0u;
+    for(int p = 0; p < out->n && g_enclosure_cull; ++p)
+    {
+      const int        k = out->order[p];
+      const trt_torus* K = &s->tori[k];
+      if(k == j || K->center[0] != J->center[0] || K->center[2] != J->center[2]) continue;
+      const double dR = (double)K->R - (double)J->R, dy = (double)K->center[1] - (double)J->center[1];
+      const double D  = sqrt(dR * dR + dy * dy);
+      if(D + (double)K->r < (double)J->r - (double)J->r * 0.0009765625) out->inside[j] |= 1u << p;
+    }
+  }
   return TRT_OK;
+}
+
+/* the camera's share of the enclosure cull: trt_api.hip primary_skip_mask */
+static uint32_t primary_skip_mask(const scene_t* S, v3 eye, float reach)
+{
+  uint32_t mask = 0u;
+  for(int j = 0; j < S->n; ++j)
+  {
+    if(S->inside[j] == 0u) continue;
+    const trt_torus* T = &S->tori[j];
+    const double ex = (double)eye.x - (double)T->center[0], ey = (double)eye.y - (double)T->center[1], ez = (double)eye.z - (double)T->center[2];
+    const double rho = sqrt(ex * ex + ez * ez) - (double)T->R;
+    const double d   = sqrt(rho * rho + ey * ey);
+    const double rc  = fabs((double)reach);
+    if(d > ((double)T->r + (double)T->r * 0.0009765625) + (rc + rc * 0.0009765625)) mask |= S->inside[j];
+  }
+  return mask;
 }
 
 /* Work counters of the calling thread (trt_stats.solved_tests / .evaluations): tests that passed
  * the bounding-volume culls of T1, and the polynomial evaluations of this file's formulation of
  * the walk (the GPU's state machine visits the same points in a different bookkeeping; only
  * solved_tests is comparable across the two). */
-static _Thread_local uint64_t tl_solved, tl_evals;
+static _Thread_local uint64_t tl_solved, tl_evals, tl_traced;
 
 /* One ray against one torus, in the scene's solver precision; result rounded to FP32. */
 static inline int torus_hit(const scene_t* S, int i, v3 o, v3 d, float dd, float inv_dd,
-                            float tmin, float tmax, float* t, uint64_t* tests)
+                            float tmin, float tmax, float* t)
 {
-  ++*tests;
+  ++tl_traced;
   int ne = 0, hit;
   if(S->f64)
   {
@@ -188,7 +237,7 @@ static inline int torus_hit(const scene_t* S, int i, v3 o, v3 d, float dd, float
 /* Closest hit over all tori (role of traceRayEXT + BVH, REFL/shaders/raytrace.rgen:64-75):
  * smallest t, first torus wins ties.  Returns torus index or -1. */
 static int closest_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, float* t_out,
-                       uint64_t* tests)
+                       uint64_t* tests, uint32_t skip)
 {
   const float dd = dot3(d, d), inv_dd = 1.0f / dd;
   int   id   = -1;
@@ -200,7 +249,9 @@ static int closest_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, flo
     const int   i  = S->order[k];
     const float tm = fminf(tmax, best);
     float t;
-    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tm, &t, tests))
+    ++*tests;
+    if((skip >> k) & 1u) continue;   /* enclosure cull: counted, not traced */
+    if(torus_hit(S, i, o, d, dd, inv_dd, tmin, tm, &t))
     {
       best = t;
       id   = i;
@@ -211,13 +262,15 @@ static int closest_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, flo
 }
 
 /* Any hit (shadow query: gl_RayFlagsTerminateOnFirstHitEXT, REFL/shaders/raytrace.rchit:114-131). */
-static int any_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, uint64_t* tests)
+static int any_hit(const scene_t* S, v3 o, v3 d, float tmin, float tmax, uint64_t* tests, uint32_t skip)
 {
   const float dd = dot3(d, d), inv_dd = 1.0f / dd;
   for(int k = 0; k < S->n; ++k)
   {
     float t;
-    if(torus_hit(S, S->order[k], o, d, dd, inv_dd, tmin, tmax, &t, tests))
+    ++*tests;
+    if((skip >> k) & 1u) continue;
+    if(torus_hit(S, S->order[k], o, d, dd, inv_dd, tmin, tmax, &t))
       return 1;
   }
   return 0;
@@ -344,7 +397,7 @@ typedef struct {
 
 static void shade_pixel(const scene_t* S, const trt_globals* g, const trt_push* pc,
                         const toro_frame* F, uint32_t W, uint32_t H, int camera, uint32_t x,
-                        uint32_t y, pixel_out* out, trt_stats* st)
+                        uint32_t y, uint32_t skip_primary, pixel_out* out, trt_stats* st)
 {
   v3 origin, direction;
   raygen(g, pc, F, W, H, camera, x, y, &origin, &direction);
@@ -358,6 +411,7 @@ static void shade_pixel(const scene_t* S, const trt_globals* g, const trt_push* 
   const v3 zero   = {0.0f, 0.0f, 0.0f};
   const v3 lp     = {pc->lightPosition[0], pc->lightPosition[1], pc->lightPosition[2]};
   out->t0 = INFINITY; out->P0 = zero; out->N0 = zero; out->id0 = -1;
+  uint32_t skip = skip_primary;                                                /* enclosure cull (above) */
 
   for(;;)                                                                      /* rgen:62 */
   {
@@ -365,7 +419,7 @@ static void shade_pixel(const scene_t* S, const trt_globals* g, const trt_push* 
     v3       nextO = origin, nextD = direction;
     float    t;
     uint64_t* ctr = depth == 0 ? &st->primary_tests : &st->bounce_tests;
-    const int id  = closest_hit(S, origin, direction, tMin, tMax, &t, ctr);    /* rgen:64-75 */
+    const int id  = closest_hit(S, origin, direction, tMin, tMax, &t, ctr, skip); /* rgen:64-75 */
     if(id < 0)
     {
       /* miss shader: REFL/shaders/raytrace.rmiss:37 (BEF rmiss:19-21: hitPosition = 0) */
@@ -403,11 +457,13 @@ static void shade_pixel(const scene_t* S, const trt_globals* g, const trt_push* 
       if(dot3(N, L) > 0.0f)                                                    /* rchit:112 */
       {
         /* shadow ray: origin O + D·t, tMin .001, tMax lightDistance (rchit:114-131) */
-        if(any_hit(S, P, L, 0.001f, lightDistance, &st->shadow_tests))
+        if(any_hit(S, P, L, 0.001f, lightDistance, &st->shadow_tests, skip | S->inside[id]))
           attenuation1 = 0.3f;                                                 /* rchit:135 */
         else
           specular = compute_specular(mat, direction, L, N);                   /* rchit:140 */
       }
+      if(dot3(N, direction) < 0.0f)   /* met from outside: whatever leaves this point by reflection leaves outwards */
+        skip |= S->inside[id];
       if(mat->illum == 3)                                                      /* rchit:145 */
       {
         attenuation.x *= mat->specular[0];                                     /* rchit:149 */
@@ -459,24 +515,27 @@ int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* sce
   if(rc) return rc;
   if(!g || !pc || !W || !H || row_end > H || row_begin > row_end) return TRT_E_INVALID;
   const toro_frame F = toroidal_frame(g, pc);
-  uint64_t np = 0, nb = 0, ns = 0, nsol = 0, nev = 0;
+  /* the camera's share of the enclosure cull: ray origins are the eye, or lie |rho| from it (BEF rgen:56) */
+  const uint32_t skip_primary = primary_skip_mask(&S, mat4_mul(g->viewInverse, 0.0f, 0.0f, 0.0f, 1.0f),
+                                                  camera == TRT_CAMERA_TOROIDAL ? pc->rho : 0.0f);
+  uint64_t np = 0, nb = 0, ns = 0, nsol = 0, nev = 0, ntr = 0;
   (void)nthreads;
   /* work items: blocks of 64 pixels of a row (fine enough to keep >100 threads busy on an 8-row band) */
   const int64_t bpr = ((int64_t)W + 63) / 64, nblk = bpr * (int64_t)(row_end - row_begin);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads > 0 ? nthreads : 1) \
-    reduction(+ : np, nb, ns, nsol, nev)
+    reduction(+ : np, nb, ns, nsol, nev, ntr)
 #endif
   for(int64_t blk = 0; blk < nblk; ++blk)
   {
     const uint32_t y  = row_begin + (uint32_t)(blk / bpr);
     const uint32_t xb = (uint32_t)(blk % bpr) * 64, xe = xb + 64 < W ? xb + 64 : W;
     trt_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
-    tl_solved = tl_evals = 0;
+    tl_solved = tl_evals = tl_traced = 0;
     for(uint32_t x = xb; x < xe; ++x)
     {
       pixel_out o;
-      shade_pixel(&S, g, pc, &F, W, H, camera, x, y, &o, &st);
+      shade_pixel(&S, g, pc, &F, W, H, camera, x, y, skip_primary, &o, &st);
       const size_t i = (size_t)y * W + x;
       if(rgba)
       {
@@ -513,6 +572,7 @@ int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* sce
     ns += st.shadow_tests;
     nsol += tl_solved;
     nev += tl_evals;
+    ntr += tl_traced;
   }
   if(stats)
   {
@@ -520,7 +580,7 @@ int oracle_render(const trt_globals* g, const trt_push* pc, const trt_scene* sce
     stats->bounce_tests  = nb;
     stats->shadow_tests  = ns;
     stats->pixels        = (uint64_t)(row_end - row_begin) * W;
-    stats->traced_tests  = np + nb + ns;   /* the oracle traces every pixel */
+    stats->traced_tests  = ntr;            /* the oracle traces every pixel: every test the enclosure cull leaves */
     stats->solved_tests  = nsol;
     stats->evaluations   = nev;
     stats->reserved      = 0;
@@ -547,7 +607,7 @@ int oracle_trace(const trt_rays* in, const trt_scene* scene, float tmin, float t
     float    t;
     uint64_t tests = 0;
     tl_solved = tl_evals = 0;
-    const int id = closest_hit(&S, o, d, tmin, tmax, &t, &tests);
+    const int id = closest_hit(&S, o, d, tmin, tmax, &t, &tests, 0u);   /* arbitrary rays: nothing is known about their origins */
     np += tests;
     nsol += tl_solved;
     nev += tl_evals;

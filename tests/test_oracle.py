@@ -220,6 +220,54 @@ def test_oracle_render_matches_golden(oracle, name, cam, prec):
     assert [stats[k] for k in ("primary_tests", "bounce_tests", "shadow_tests")] == z["stats"].tolist()
 
 
+def test_enclosure_cull_changes_nothing(oracle):
+    """T3's enclosure cull (trt_oracle.c: a query skips the tori whose tube lies strictly inside a tube its ray starts
+    outside of) against the same oracle with the cull switched off — every torus tested by every query: images, first-hit
+    records, RenderedData and the three query counts are identical bit for bit; only the tests a lane executes go down.
+    The golden frames (rendered before the cull existed) pin the same thing from the other side
+    (test_oracle_render_matches_golden).  Scenes: config 4's nest, nests beside and around other tori, a camera BETWEEN
+    two shells, shells that differ in R and in height, the toroidal camera inside and outside a nest, both precisions."""
+    rng = np.random.default_rng(77)
+    W = H = 48
+    P, M = camera.PLASTIC, camera.MIRROR
+    scenes = [camera.nested_tori_scene()]
+    scenes.append(abi.Scene([((0, 0, 0), 1.0, 0.4, 1), ((0, 0, 0), 1.05, 0.3, 0), ((0, 0.05, 0), 0.97, 0.2, 1), ((0, 0, 0), 1.0, 0.1, 0),
+                             ((2.5, 0, 0), 0.6, 0.2, 1), ((2.5, 0, 0), 0.6, 0.1, 0)], [P, M]))
+    scenes.append(abi.Scene([((0, 0, 0), 2.0, 1.2, 1), ((0, 0, 0), 2.0, 0.5, 1), ((0, 0, 0), 2.0, 0.2, 0)], [P, M]))   # eye may sit between shells
+    for _ in range(4):
+        n = int(rng.integers(2, 9))
+        R0 = float(rng.uniform(0.8, 1.5))
+        tori = []
+        for i in range(n):
+            r = float(rng.uniform(0.05, 0.6))
+            tori.append(((0.0, float(rng.uniform(-0.05, 0.05)) if i % 2 else 0.0, 0.0), R0 + float(rng.uniform(-0.05, 0.05)), min(r, 0.7), int(rng.integers(0, 2))))
+        scenes.append(abi.Scene(tori, [P, M]))
+    eyes = [(0.0, 1.5, -4.0), (0.0, 0.2, -2.9), (1.1, 0.0, 0.0), (0.3, 2.5, 0.4)]   # outside, close, inside the tubes, above the hole
+    n_culled = 0
+    for si, sc in enumerate(scenes):
+        for ei, eye in enumerate(eyes):
+            for cam in (abi.TRT_CAMERA_PINHOLE, abi.TRT_CAMERA_TOROIDAL):
+                g = camera.globals_for(eye, (0.0, 0.0, 0.0) if cam == abi.TRT_CAMERA_PINHOLE else (3.0, 0.1, 0.5), W, H)
+                pc = abi.make_push(max_depth=4, rho=0.3 if cam == abi.TRT_CAMERA_TOROIDAL else 0.0,
+                                   light_type=(si + ei) % 2)
+                prec = abi.TRT_SOLVE_F64 if (si + ei) % 3 == 0 else abi.TRT_SOLVE_F32
+                try:
+                    oracle.set_enclosure_cull(0)
+                    a = oracle.render(sc, g, pc, W, H, cam, precision=prec, want_rendered=True, nthreads=4)
+                finally:
+                    oracle.set_enclosure_cull(1)
+                b = oracle.render(sc, g, pc, W, H, cam, precision=prec, want_rendered=True, nthreads=4)
+                np.testing.assert_array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+                for k in abi.HIT_FIELDS + ("id",):
+                    np.testing.assert_array_equal(a[1][k].view(np.uint32), b[1][k].view(np.uint32))
+                np.testing.assert_array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+                for k in ("primary_tests", "bounce_tests", "shadow_tests", "pixels"):
+                    assert a[3][k] == b[3][k], (si, ei, cam, k)
+                assert b[3]["traced_tests"] <= a[3]["traced_tests"] and b[3]["solved_tests"] <= a[3]["solved_tests"]
+                n_culled += a[3]["traced_tests"] - b[3]["traced_tests"]
+    assert n_culled > 0
+
+
 def test_pinhole_raygen_vectors(oracle):
     """k8: identity viewInverse/projInverse -> origin 0, direction normalize((dx,dy,1))
     (REFL/shaders/raytrace.rgen:42-48)."""

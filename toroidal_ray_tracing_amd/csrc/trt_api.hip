@@ -222,6 +222,24 @@ int build_scene_uncached(trt_ctx* ctx, const trt_scene* s, SceneK& out)
     }
     out.order[k] = (int)i;
   }
+  // Enclosure masks: tube k lies strictly inside tube j when both tori turn about the same axis line
+  // (centre x and z equal) and every point of k's centre circle is closer to j's than r_j - r_k, with 2^-10 of r_j to
+  // spare: the circles are sqrt(dR² + dy²) apart everywhere.  Plain double arithmetic on the scene's floats — the
+  // oracle takes the same decisions (oracle/trt_oracle.c scene_prepare).  Bit positions are TEST-ORDER positions.
+  for(uint32_t j = 0; j < s->n_tori; ++j)
+  {
+    out.inside[j] = 0u;
+    const trt_torus& J = s->tori[j];
+    for(uint32_t p = 0; p < s->n_tori; ++p)
+    {
+      const uint32_t k = (uint32_t)out.order[p];
+      const trt_torus& K = s->tori[k];
+      if(k == j || K.center[0] != J.center[0] || K.center[2] != J.center[2]) continue;
+      const double dR = (double)K.R - (double)J.R, dy = (double)K.center[1] - (double)J.center[1];
+      const double D  = std::sqrt(dR * dR + dy * dy);
+      if(D + (double)K.r < (double)J.r - (double)J.r * 0.0009765625 && !ctx->tn.no_enclosure) out.inside[j] |= 1u << p;
+    }
+  }
   for(uint32_t i = 0; i < s->n_materials; ++i)
   {
     const trt_material& m = s->materials[i];
@@ -243,6 +261,26 @@ void mat4_origin(const float* m, float out[3])
 {
   for(int r = 0; r < 3; ++r)
     out[r] = std::fma(m[12 + r], 1.0f, std::fma(m[8 + r], 0.0f, std::fma(m[4 + r], 0.0f, m[r] * 0.0f)));
+}
+
+// Enclosure cull, the camera's share: the tori no primary ray of the frame can hit first — the tubes inside every tube j
+// that all ray origins lie outside of.  The origins are the eye (pinhole) or lie `reach` = |rho| from it (toroidal camera,
+// BEF rgen:56); certified when the eye's distance from j's centre circle exceeds r_j + reach with 2^-10 of each to spare.
+// Double arithmetic on the same FP32 eye the kernels compute (mat4_origin); the oracle repeats it (shade setup).
+uint32_t primary_skip_mask(const trt_scene* s, const SceneK& K, const float eye[3], float reach)
+{
+  uint32_t mask = 0u;
+  for(uint32_t j = 0; j < s->n_tori; ++j)
+  {
+    if(K.inside[j] == 0u) continue;
+    const trt_torus& T = s->tori[j];
+    const double ex = (double)eye[0] - (double)T.center[0], ey = (double)eye[1] - (double)T.center[1], ez = (double)eye[2] - (double)T.center[2];
+    const double rho = std::sqrt(ex * ex + ez * ez) - (double)T.R;
+    const double d   = std::sqrt(rho * rho + ey * ey);
+    const double rc  = std::fabs((double)reach);
+    if(d > ((double)T.r + (double)T.r * 0.0009765625) + (rc + rc * 0.0009765625)) mask |= K.inside[j];
+  }
+  return mask;
 }
 
 constexpr float kDeg2Rad = 0.017453292519943295f;  // GLSL radians()
@@ -396,6 +434,7 @@ extern "C" int trt_debug_reload_tuning(trt_ctx* ctx)
 {
   if(!ctx) return TRT_E_INVALID;
   ctx->tn = tuning_from_env();
+  ctx->scene_cache.valid = false;   // (TRT_NO_ENCLOSURE changes the scene constants)
   return TRT_OK;
 }
 #endif
@@ -656,6 +695,11 @@ int render_frames(trt_ctx* ctx, const trt_frame* frames, uint32_t n_frames, cons
     if(camera == TRT_CAMERA_TOROIDAL)
       if(int rc = build_toro(ctx, *fr.g, *fr.pc, W, H, st, a.toro, f > 0)) return rc;
     if(ctx->stats_on) a.stats = ctx->d_stats;
+    {
+      float eye[3];
+      mat4_origin(fr.g->viewInverse, eye);
+      a.skip_primary = primary_skip_mask(scene, S, eye, camera == TRT_CAMERA_TOROIDAL ? fr.pc->rho : 0.0f);
+    }
     if(!lists) continue;
     a.tiles_live  = (uint32_t*)ctx->d_tiles.p;
     a.tiles_clear = a.tiles_live + n_tiles * n_frames;

@@ -90,6 +90,8 @@ struct SceneK {
   int            f64;   // 1: FP64 root solve (BASELINE config 4), FP32 I/O
   int            dk;    // 0: Fourier–Newton walk; alternative root solvers: 1 Durand–Kerner, 2 Ferrari
   int            order[TRT_MAX_TORI];  // test order: descending bounding radius R + r, ties by index
+  uint32_t       inside[TRT_MAX_TORI]; // inside[i]: the tori whose tube lies strictly inside torus i's tube, as a mask over TEST-ORDER
+                                       // positions (bit k = order[k]) — what a ray that leaves i's surface outwards cannot hit first
   TorusK<float>  k32[TRT_MAX_TORI];
   TorusK<double> k64[TRT_MAX_TORI];
   TorusShade     shade[TRT_MAX_TORI];
@@ -97,21 +99,32 @@ struct SceneK {
 };
 
 // Copy the scene constants from the kernel-argument segment into LDS — only the records in use
-// (header + test order, n_tori solver records of the active precision, n_tori shading records,
-// n_mat materials): 38 dwords for one FP32 torus instead of the 380 of the full struct, one load per thread.
+// (header + test order + enclosure masks, n_tori solver records of the active precision, n_tori shading records,
+// n_mat materials): 46 dwords for one FP32 torus instead of the 388 of the full struct, one load per thread.
 // Reads in the hot loops then hit LDS at wave-uniform (broadcast) or material-indexed addresses.
+// The dwords of a SceneK that are in use, numbered 0 .. scene_words() - 1: word i of them sits at dword scene_word(i) of the struct.
+constexpr uint32_t kSceneHdr = 20, kSceneK32 = kSceneHdr, kSceneK64 = kSceneK32 + 80, kSceneShade = kSceneK64 + 160, kSceneMat = kSceneShade + 40;
+__device__ __forceinline__ uint32_t scene_words(const SceneK& arg)
+{
+  return kSceneHdr + (arg.f64 ? 20u : 10u) * (uint32_t)arg.n_tori + 5u * (uint32_t)arg.n_tori + 11u * (uint32_t)arg.n_mat;
+}
+__device__ __forceinline__ uint32_t scene_word(const SceneK& arg, uint32_t i)
+{
+  const uint32_t n = (uint32_t)arg.n_tori;
+  const uint32_t c0 = kSceneHdr, c1 = c0 + (arg.f64 ? 0u : 10u * n), c2 = c1 + (arg.f64 ? 20u * n : 0u), c3 = c2 + 5u * n;
+  return i < c0 ? i : i < c1 ? kSceneK32 + (i - c0) : i < c2 ? kSceneK64 + (i - c1) : i < c3 ? kSceneShade + (i - c2) : kSceneMat + (i - c3);
+}
 __device__ __forceinline__ void stage_scene(SceneK* lds, const SceneK& arg)
 {
-  static_assert(sizeof(SceneK) == 4 * (12 + 80 + 160 + 40 + 88) && sizeof(TorusK<float>) == 40 && sizeof(TorusShade) == 20
-                    && sizeof(MaterialK) == 44, "SceneK layout");
+  static_assert(sizeof(SceneK) == 4 * (kSceneMat + 88) && sizeof(TorusK<float>) == 40 && sizeof(TorusShade) == 20
+                    && sizeof(MaterialK) == 44 && offsetof(SceneK, k32) == 4 * kSceneK32 && offsetof(SceneK, k64) == 4 * kSceneK64
+                    && offsetof(SceneK, shade) == 4 * kSceneShade && offsetof(SceneK, mat) == 4 * kSceneMat, "SceneK layout");
   const uint32_t* src = reinterpret_cast<const uint32_t*>(&arg);
   uint32_t*       dst = reinterpret_cast<uint32_t*>(lds);
-  const uint32_t  n = (uint32_t)arg.n_tori, nm = (uint32_t)arg.n_mat;
-  const uint32_t  c0 = 12, c1 = c0 + (arg.f64 ? 0u : 10u * n), c2 = c1 + (arg.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
-                 c4 = c3 + 11u * nm;
+  const uint32_t  c4 = scene_words(arg);
   for(uint32_t i = threadIdx.x; i < c4; i += blockDim.x)
   {
-    const uint32_t off = i < c0 ? i : i < c1 ? 12u + (i - c0) : i < c2 ? 92u + (i - c1) : i < c3 ? 252u + (i - c2) : 292u + (i - c3);
+    const uint32_t off = scene_word(arg, i);
     dst[off] = src[off];
   }
   __syncthreads();
@@ -672,10 +685,12 @@ __device__ __forceinline__ bool torus_hit(const SceneK& S, int i, const RayK<Rea
 // Tori are tested in S.order (largest bounding sphere first) and the interval of every later
 // test ends at the closest hit so far: behind an enclosing shell the remaining tests end in
 // their window clip without a Newton step.  Equal t keeps the torus tested first.
+// `skip` (a mask over test-order positions) names the tori this ray cannot hit first: tubes that lie strictly inside a
+// tube the ray's origin is known to be OUTSIDE of (enclosure cull) — they count as tests and cost nothing.
 // Returns the torus index or -1; `tests` counts ray–torus tests.
 template <class Real, bool DK = false, int WALK = kRenderWalk>
 __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
-                                           float& t_out, uint32_t& tests, WorkCount& wc)
+                                           float& t_out, uint32_t& tests, WorkCount& wc, uint32_t skip = 0u)
 {
   RayK<Real> r;
   r.set(o, d, tmin, tmax);
@@ -686,6 +701,8 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
     const int i = S.order[k];
     float t;
     ++tests;
+    if((skip >> k) & 1u)
+      continue;
 #ifdef TRT_FULL_WINDOW   // timing experiment only (the tail of config 4): every torus over the FULL interval, minimum afterwards
     if(torus_hit<Real, DK, WALK>(S, i, r, tmin, tmax, t, wc) && t < best)
 #else
@@ -703,7 +720,7 @@ __device__ __forceinline__ int closest_hit(const SceneK& S, v3 o, v3 d, float tm
 // Any hit — the shadow query with gl_RayFlagsTerminateOnFirstHitEXT (REFL/shaders/raytrace.rchit:114-131).
 template <class Real, bool DK = false>
 __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin, float tmax,
-                                        uint32_t& tests, WorkCount& wc)
+                                        uint32_t& tests, WorkCount& wc, uint32_t skip = 0u)
 {
   RayK<Real> r;
   r.set(o, d, tmin, tmax);
@@ -711,6 +728,8 @@ __device__ __forceinline__ bool any_hit(const SceneK& S, v3 o, v3 d, float tmin,
   {
     float t;
     ++tests;
+    if((skip >> k) & 1u)
+      continue;
     if(torus_hit<Real, DK>(S, S.order[k], r, tmin, tmax, t, wc))
       return true;
   }

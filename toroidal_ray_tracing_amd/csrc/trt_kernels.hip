@@ -232,13 +232,11 @@ __device__ __forceinline__ void stage_block256(SceneK* S, RenderArgs* A, const S
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&scene);
     uint32_t*       dst = reinterpret_cast<uint32_t*>(S);
-    const uint32_t  n = (uint32_t)scene.n_tori, nm = (uint32_t)scene.n_mat;
-    const uint32_t  c0 = 12, c1 = c0 + (scene.f64 ? 0u : 10u * n), c2 = c1 + (scene.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
-                   c4 = c3 + 11u * nm;
+    const uint32_t  c4 = scene_words(scene);
 #pragma unroll 1
     for(uint32_t i = tid - 128u; i < c4; i += 128u)
     {
-      const uint32_t off = i < c0 ? i : i < c1 ? 12u + (i - c0) : i < c2 ? 92u + (i - c1) : i < c3 ? 252u + (i - c2) : 292u + (i - c3);
+      const uint32_t off = scene_word(scene, i);
       dst[off] = src[off];
     }
   }
@@ -375,11 +373,15 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
   asm volatile("v_mov_b32 %0, 1.0" : "=v"(one0));
   v3  attenuation = {one0, one0, one0};                                    // rgen:56
   v3  hitValue    = {0.0f, 0.0f, 0.0f};                                    // rgen:61
+  // enclosure cull (trt_device.hpp closest_hit): the tori this path's rays cannot hit first — tubes strictly inside a tube
+  // the ray origin is outside of.  The camera's share is certified per frame on the host; a hit left OUTWARDS adds the
+  // tubes inside the torus hit (outside-ness persists along a path: a segment that ended on a surface crossed none).
+  uint32_t skip = a.skip_primary;
   for(;;)                                                                  // rgen:62
   {
     v3    prdHit, nextO = origin, nextD = direction;
     float t;
-    const int id = closest_hit<Real, DK>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce, wc);
+    const int id = closest_hit<Real, DK>(S, origin, direction, kTMin, kTMax, t, depth == 0 ? n_primary : n_bounce, wc, skip);
     if(id < 0)
     {
       prdHit = {a.pc.clearColor[0] * 0.8f, a.pc.clearColor[1] * 0.8f, a.pc.clearColor[2] * 0.8f};  // rmiss:37
@@ -405,8 +407,11 @@ __device__ __forceinline__ void trace_pixel(const SceneK& S, const RenderArgs& a
         if(rd) rd.put(0, make_float4(h.P.x, h.P.y, h.P.z, 1.0f));          // BEF rgen:112
       }
       bool shadowed = false;
-      if(h.wantShadow)
-        shadowed = any_hit<Real, DK>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow, wc);  // rchit:114-131
+      const uint32_t inside = S.inside[id];
+      if(h.wantShadow)   // (N·L > 0: the shadow ray leaves the surface outwards)
+        shadowed = any_hit<Real, DK>(S, h.P, h.L, kTMin, h.lightDistance, n_shadow, wc, skip | inside);  // rchit:114-131
+      if(dot3(h.N, direction) < 0.0f)   // hit from outside: reflect(D, N) leaves outwards
+        skip |= inside;
       prdHit = hit_end(S, h, direction, shadowed, attenuation, done, nextO, nextD);
     }
     hitValue.x = fma_(prdHit.x, attenuation.x, hitValue.x);                // rgen:76
@@ -1015,6 +1020,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
   v3       dir_in = {0.0f, 0.0f, 0.0f};  // direction of the ray whose closest hit is being shaded
   // lane state: current query
   int   kind = K_NONE, ti = 0, best_id = -1;
+  uint32_t skip_path = 0u, skip_q = 0u;   // enclosure cull (trace_pixel): the path's mask, and the current query's
   float best_t = 0.0f, q_tmax = 0.0f;
   bool  shadow_hit = false;
   v3    qo = {0.0f, 0.0f, 0.0f}, qd = {0.0f, 0.0f, 0.0f};  // query ray (FP32)
@@ -1088,6 +1094,9 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
               if(rd) st4(rd, make_float4(h.P.x, h.P.y, h.P.z, 1.0f));
             }
             dir_in = qd;
+            const uint32_t inside = S.inside[best_id];
+            skip_q = skip_path | inside;                    // the shadow ray leaves the surface outwards (N·L > 0)
+            if(dot3(h.N, qd) < 0.0f) skip_path |= inside;   // hit from outside: the reflected ray leaves outwards
             hN = h.N; hDiffuse = h.diffuse; hLightI = h.lightIntensity; hMat = h.matId;
             qo = h.P; qd = h.L; q_tmax = h.lightDistance;
             if(h.wantShadow)
@@ -1133,6 +1142,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
           {
             done = 1;                                                        // rgen:84
             kind = K_CLOSEST; ti = 0; best_id = -1; best_t = __builtin_inff(); shadow_hit = false;
+            skip_q = skip_path;
             q_tmax = kTMax;
             rk.set(qo, qd, kTMin, kTMax);                                    // rgen:82-83
           }
@@ -1171,6 +1181,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
             attenuation = {1.0f, 1.0f, 1.0f};
             hitValue    = {0.0f, 0.0f, 0.0f};
             kind = K_CLOSEST; ti = 0; best_id = -1; best_t = __builtin_inff(); shadow_hit = false;
+            skip_path = skip_q = a.skip_primary;
             q_tmax = kTMax;
             rk.set(qo, qd, kTMin, kTMax);
           }
@@ -1199,6 +1210,10 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         if(kind == K_SHADOW) ++n_shadow;
         else if(depth == 0) ++n_primary;
         else ++n_bounce;
+        if((skip_q >> ti) & 1u)
+          ++ti;  // a tube this ray cannot hit first (enclosure cull): counted, not traced
+        else
+        {
         ++wc.traced;
         // closest-hit queries end the interval of every later test at the closest hit so far
         if(tst.setup((Real)rk.ox, (Real)rk.oy, (Real)rk.oz, (Real)rk.dx, (Real)rk.dy, (Real)rk.dz, rk.dd, rk.inv_dd, (Real)rk.tmin,
@@ -1209,6 +1224,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 4 ? 4 : 2)) void render_persi
         }
         else
           ++ti;  // culled by the bounding sphere / window: this test is a miss
+        }
       }
     }
     if(!__any(inflight))
@@ -1320,13 +1336,11 @@ __global__ __launch_bounds__(256, (DK ? 2 : (sizeof(Real) == 4 ? TRT_LISTED_WAVE
     {
       const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(&scene);
       uint32_t*       sdst = reinterpret_cast<uint32_t*>(&S);
-      const uint32_t  n = (uint32_t)scene.n_tori, nm = (uint32_t)scene.n_mat;
-      const uint32_t  c0 = 12, c1 = c0 + (scene.f64 ? 0u : 10u * n), c2 = c1 + (scene.f64 ? 20u * n : 0u), c3 = c2 + 5u * n,
-                     c4 = c3 + 11u * nm;
+      const uint32_t  c4 = scene_words(scene);
 #pragma unroll 1
       for(uint32_t i = threadIdx.x - 128u; i < c4; i += 128u)
       {
-        const uint32_t off = i < c0 ? i : i < c1 ? 12u + (i - c0) : i < c2 ? 92u + (i - c1) : i < c3 ? 252u + (i - c2) : 292u + (i - c3);
+        const uint32_t off = scene_word(scene, i);
         sdst[off] = ssrc[off];
       }
     }
@@ -2043,6 +2057,7 @@ Tuning tuning_from_env()
   u32("TRT_MIN_BATCH", t.min_batch);
   i32("TRT_FINE_CLASSIFY", t.fine);
   if(getenv("TRT_NO_TILE_CULL")) t.no_tile_cull = 1;
+  if(getenv("TRT_NO_ENCLOSURE")) t.no_enclosure = 1;
   u32("TRT_DEBUG_SKIP", t.debug_skip);
   u32("TRT_HEAVY_X16", t.heavy_x16);
   u32("TRT_HEAVY_MIN_TORI", t.heavy_min_tori);

@@ -48,6 +48,8 @@ struct RenderArgs {
   uint32_t            fine;         // 1: classify per 8×8 tile with the distance-function march (toroidal camera)
   uint32_t            debug_skip;   // -DTRT_TUNING builds only (TRT_DEBUG_SKIP): 1 = skip clear tiles, 2 = skip traced tiles
   uint32_t            vec4_ok;      // W % 4 == 0 and all first-hit streams 16-B aligned: dwordx4 clears
+  uint32_t            skip_primary; // enclosure cull: test-order mask of the tori no primary ray of this frame can hit first (tubes strictly
+                                    // inside a tube every ray origin of the frame lies outside of; certified on the host, trt_api.hip)
 };
 
 // A batch of frames rendered by ONE pair of launches (trt_render_batch_dev): the frames share the scene, the size, the
@@ -69,6 +71,7 @@ struct Tuning {
   int      fine               = -1;   // TRT_FINE_CLASSIFY: -1 = chosen per frame (camera model / eye position)
   int      no_tile_cull       = 0;    // TRT_NO_TILE_CULL
   uint32_t debug_skip         = 0;    // TRT_DEBUG_SKIP (timing ablations: the frame is then INCOMPLETE)
+  int      no_enclosure       = 0;    // TRT_NO_ENCLOSURE: no enclosure cull (every torus tested by every query; same images, A/B timing)
   int      debug_tiles        = 0;    // TRT_DEBUG_TILES: print the list lengths after every frame (synchronises)
   uint32_t heavy_x16          = 24;   // TRT_HEAVY_X16: a macro tile is HEAVY above heavy_x16/16 (1.5) x the mean cost; 0 = no cost feedback
   uint32_t heavy_min_tori     = 2;    // TRT_HEAVY_MIN_TORI: cost feedback only for scenes with at least this many tori (below)
