@@ -520,7 +520,9 @@ def worker(a, world, rank, local):
         # HIP events on the launch stream (torch's current stream IS the stream handed to trt_render*_dev, and the stream a
         # graph is replayed on).  One pair around each step's F frames; with a gather after EVERY frame a pair around every
         # frame's render launches instead, because the stream then also carries the waits on the gathers.
-        per_frame = multi and frame.gather and frame.gather_every == 1 and not graphed and frame.batch == 1
+        # (only with ONE render stream: frames on several streams overlap, and the sum of their event pairs would count
+        # the shared time once per stream — ADVICE r02)
+        per_frame = multi and frame.gather and frame.gather_every == 1 and not graphed and frame.batch == 1 and len(frame.trs) == 1
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(steps * (F if per_frame else 1))]
         sync_all()

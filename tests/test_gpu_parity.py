@@ -871,6 +871,17 @@ def random_case(seed):
     pc = abi.make_push(clear=tuple(rng.uniform(0.0, 1.0, 3)) + (1.0,), light_pos=tuple(rng.uniform(-12.0, 16.0, 3)),
                        light_intensity=float(rng.uniform(10.0, 200.0)), light_type=int(rng.integers(0, 2)),
                        max_depth=int(rng.integers(1, 7)), rho=float(rng.uniform(0.5, 5.0)))
+    if n > 1 and int(rng.integers(0, 3)) == 0:
+        # every third scene: the tori share an axis line — shells inside, around and across one another, slightly
+        # different R and heights (what the enclosure cull of T3 works on); sometimes the eye sits among the shells
+        c0, R0 = tori[0][0], tori[0][1]
+        tori = [((c0[0], c0[1] + (float(rng.uniform(-0.05, 0.05)) * R0 if i % 2 else 0.0), c0[2]), R0 * (1.0 + float(rng.uniform(-0.03, 0.03))),
+                 float(rng.uniform(0.04, 0.9)) * R0 * 0.97, t_[3]) for i, t_ in enumerate(tori)]
+        sc = abi.Scene(tori, mats)
+        if int(rng.integers(0, 4)) == 0:
+            a_ = float(rng.uniform(0.0, 6.28))
+            eye = (c0[0] + R0 * np.cos(a_) * float(rng.uniform(0.7, 1.3)), c0[1] + float(rng.uniform(-0.3, 0.3)) * R0, c0[2] + R0 * np.sin(a_) * float(rng.uniform(0.7, 1.3)))
+            g = camera.globals_for(eye, center, W, H, fov_deg=float(rng.uniform(20.0, 110.0)))
     return sc, g, pc, W, H, int(toroidal)
 
 
