@@ -258,7 +258,7 @@ def test_enclosure_cull_changes_nothing(oracle):
                     oracle.set_enclosure_cull(1)
                 b = oracle.render(sc, g, pc, W, H, cam, precision=prec, want_rendered=True, nthreads=4)
                 np.testing.assert_array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-                for k in abi.HIT_FIELDS + ("id",):
+                for k in abi.HIT_FIELDS:
                     np.testing.assert_array_equal(a[1][k].view(np.uint32), b[1][k].view(np.uint32))
                 np.testing.assert_array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
                 for k in ("primary_tests", "bounce_tests", "shadow_tests", "pixels"):
