@@ -225,7 +225,7 @@ int build_scene_uncached(trt_ctx* ctx, const trt_scene* s, SceneK& out)
   // Enclosure masks: tube k lies strictly inside tube j when both tori turn about the same axis line
   // (centre x and z equal) and every point of k's centre circle is closer to j's than r_j - r_k, with 2^-10 of r_j to
   // spare: the circles are sqrt(dR² + dy²) apart everywhere.  Plain double arithmetic on the scene's floats — the
-  // oracle takes the same decisions (oracle/trt_oracle.c scene_prepare).  Bit positions are TEST-ORDER positions.
+  // tests' CPU checker takes the same decisions from the same lines.  Bit positions are TEST-ORDER positions.
   for(uint32_t j = 0; j < s->n_tori; ++j)
   {
     out.inside[j] = 0u;
