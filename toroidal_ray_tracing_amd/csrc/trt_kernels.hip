@@ -1446,7 +1446,17 @@ __device__ __forceinline__ void post_pixel(float4 c, uint64_t i, float4* __restr
   // the framebuffer's alpha is 1 (rgen:87) and post_gamma(1) is exactly 1 (log2_poly(1) = 0,
   // exp2_poly(0) = 1): when the whole wave sees alpha 1 the fourth pow is skipped
   const float ow = __all(c.w == 1.0f) ? 1.0f : post_gamma(c.w);
-  const float4 o = make_float4(post_gamma(c.x), post_gamma(c.y), post_gamma(c.z), ow);
+  // a wave whose 64 pixels are all grey (r = g = b: the clear colour of the baseline frame, 85 % of its pixels) computes ONE
+  // pow per pixel instead of three — the same bits, post_gamma being a function of its argument alone
+  const bool  grey = __all(c.x == c.y && c.y == c.z);
+  const float ox = post_gamma(c.x);
+  float oy = ox, oz = ox;
+  if(!grey)
+  {
+    oy = post_gamma(c.y);
+    oz = post_gamma(c.z);
+  }
+  const float4 o = make_float4(ox, oy, oz, ow);
   if(f32_out) f32_out[i] = o;
   if(u8_out)
   {
