@@ -113,6 +113,9 @@ typedef struct trt_torus {
   int32_t matId;
 } trt_torus; /* 24 bytes */
 
+/* Tori may intersect and may be nested (BASELINE config 4: eight shells of one tube).  trt_render* skips, for a ray that
+ * starts outside a tube, the tori whose tube lies strictly inside it — they cannot be the closest hit;
+ * results and query counts are those of testing every torus.  trt_trace tests every torus for every ray. */
 typedef struct trt_scene {
   const trt_torus*    tori;
   uint32_t            n_tori;      /* 1..TRT_MAX_TORI      */
