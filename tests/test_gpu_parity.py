@@ -213,6 +213,48 @@ def test_render_parity(tr, oracle, name, variant):
     assert q(st) == q(wstats)
 
 
+def _nests():
+    P, M = camera.PLASTIC, camera.MIRROR
+    return [camera.nested_tori_scene(),
+            abi.Scene([((0, 0, 0), 1.0, 0.4, 1), ((0, 0, 0), 1.05, 0.3, 0), ((0, 0.05, 0), 0.97, 0.2, 1), ((0, 0, 0), 1.0, 0.1, 0),
+                       ((2.5, 0, 0), 0.6, 0.2, 1), ((2.5, 0, 0), 0.6, 0.1, 0)], [P, M]),      # a nest beside a nest
+            abi.Scene([((0, 0, 0), 2.0, 1.2, 1), ((0, 0, 0), 2.0, 0.5, 1), ((0, 0, 0), 2.0, 0.2, 0)], [P, M])]   # room for an eye between shells
+
+
+@pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
+@pytest.mark.parametrize("scene", [0, 1, 2])
+def test_enclosure_cull_scenes(tr, oracle, scene, variant):
+    """T3's enclosure cull on the GPU against the oracle (which implements the same rule, and is itself checked against
+    "every torus tested" in tests/test_oracle.py): nests seen from outside, from close by, from BETWEEN two shells (the
+    eye inside the outer tube: nothing may be skipped for primary rays there) and from above the hole, both cameras — the
+    toroidal one with its ray origins on a circle around the eye —, first-hit records bit for bit, query counts equal,
+    and fewer tests executed than queries x tori wherever something is enclosed."""
+    sc = _nests()[scene]
+    W, H = 120, 88
+    tr.set_render_variant(variant)
+    tr.enable_stats(True)
+    culled = 0
+    try:
+        for ei, eye in enumerate([(0.0, 1.5, -4.0), (0.0, 0.2, -2.9), (2.9, 0.0, 0.0) if scene == 2 else (1.1, 0.0, 0.0), (0.3, 2.5, 0.4)]):
+            for cam in (abi.TRT_CAMERA_PINHOLE, abi.TRT_CAMERA_TOROIDAL):
+                g = camera.globals_for(eye, (0.0, 0.0, 0.0) if cam == abi.TRT_CAMERA_PINHOLE else (3.0, 0.1, 0.5), W, H)
+                pc = abi.make_push(max_depth=4, rho=0.3 if cam == abi.TRT_CAMERA_TOROIDAL else 0.0, light_type=ei % 2)
+                prec = abi.TRT_SOLVE_F64 if (ei + scene) % 2 else abi.TRT_SOLVE_F32
+                tr.set_solver(prec)
+                _, _, wstats = check_render(tr, oracle, sc, g, pc, W, H, cam, prec)
+                st = tr.stats()
+                assert q(st) == q(wstats), (scene, ei, cam)
+                if variant == "static":   # every pixel traced: the tests a lane executed are the oracle's
+                    all_tests = sum(q(st)[k] for k in ("primary_tests", "bounce_tests", "shadow_tests"))
+                    assert st["traced_tests"] == wstats["traced_tests"] <= all_tests
+                    culled += all_tests - st["traced_tests"]
+        assert variant != "static" or culled > 0
+    finally:
+        tr.set_solver(abi.TRT_SOLVE_F32)
+        tr.enable_stats(False)
+        tr.set_render_variant("listed")
+
+
 @pytest.mark.parametrize("variant", ["static", "persistent", "listed"])
 def test_render_fp64_nested(tr, oracle, variant):
     W, H = 160, 120
