@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """MEASURED bound of what re-ordering rays can buy trt_trace on incoherent rays: bench.py's aimed set (2^20 rays) traced in its
 own order and in orders that only an oracle could produce — sorted by each ray's TRUE walk length (polynomial evaluations of
-the CPU restatement; tools/_aimed_ev.npz, made by the snippet in this file's history) inside windows of W rays and over the
+the CPU restatement; tools/_aimed_ev.npz, made by tools/make_aimed_ev.py on the CPU) inside windows of W rays and over the
 whole set.  Same rays, same arithmetic, permuted consistently: only the company a ray keeps in its wave changes.
 usage: trace_sorted.py"""
 import os, statistics, sys
