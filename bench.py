@@ -350,7 +350,7 @@ def secondary(tr, dev, stream):
     ms = timeit(lambda: tr.splat_dev(cloud.data_ptr(), n, vp, 2048, 2048, img2.data_ptr(), stream=s), reps=5)
     by = 32 * n + 24 * 2048 * 2048
     res.append({"name": "re-projection (SEC), 8.4 M random points -> 2048^2", "ms": ms, "units": n, "GB_per_s": by / ms / 1e6,
-                "frac_hbm": by / ms / 1e6 / HBM_PEAK_GBPS, "dtype": "u64 keys", "bound": "hbm", "kernel": "splat_count/scan/scatter/resolve_bins",
+                "frac_hbm": by / ms / 1e6 / HBM_PEAK_GBPS, "dtype": "u64 keys", "bound": "hbm", "kernel": "splat_bin + splat_resolve_bins (paged scatter)",
                 "points_per_s": n / ms * 1e3})
     del cloud, img2
     o8 = torch.empty(W, W, 4, dtype=torch.uint8, device=dev)

@@ -1326,6 +1326,33 @@ def test_splat_bit_exact(tr, oracle):
             want = oracle.splat(pts2, vp2, W2, H2, point_size=size)
             np.testing.assert_array_equal(out2.cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=f"{W2}x{H2} point_size {size}")
         del d2, out2
+    # crowded bins: the paged scatter hands a bin page after page (a 2048² image has 512 bins, a page holds 4,096 records
+    # for a cloud of this size): everything inside one bin, on a corner shared by four bins with big points (four records
+    # per point), and a sheet in screen order (a block's whole run goes to one bin and spans pages) — a hundred window
+    # rotations per bin, every one bit for bit
+    W3 = H3 = 2048
+    vp3 = camera.perspective_vk(60, 1.0) @ camera.look_at((0.0, 0.0, 5.0), (0, 0, 0))
+    out3 = torch.empty(H3, W3, 4, device=dev)
+    for kind, n3, size in (("cluster", 400_000, 2.5), ("corner", 150_000, 31.0), ("sheet", 400_000, 1.0)):
+        pts3 = np.zeros((n3, 8), np.float32)
+        u = rng.uniform(0, 1, (n3, 3))
+        if kind == "cluster":
+            pts3[:, :3] = (u - 0.5) * 0.05 + np.array([0.3, 0.2, 0.0])
+        elif kind == "corner":
+            pts3[:, :3] = (u - 0.5) * 0.02
+        else:
+            k3 = np.arange(n3); side = int(n3 ** 0.5) + 1
+            pts3[:, 0] = ((k3 % side) / side - 0.5) * 5; pts3[:, 1] = ((k3 // side) / side - 0.5) * 5; pts3[:, 2] = u[:, 2] * 0.01
+        pts3[:, 4:7] = rng.uniform(0, 1, (n3, 3))
+        pts3[n3 // 2:n3 // 2 + 3000] = pts3[:3000]
+        d3 = torch.from_numpy(pts3).to(dev)
+        for rep in range(2):   # twice: the second call finds the bins' words and the pool as the first left them
+            tr.splat_dev(d3.data_ptr(), n3, vp3, W3, H3, out3.data_ptr(), point_size=size, stream=s)
+        torch.cuda.synchronize()
+        want = oracle.splat(pts3, vp3, W3, H3, point_size=size)
+        np.testing.assert_array_equal(out3.cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=f"crowded: {kind}")
+        del d3
+    del out3
     # no points at all: the clear colour everywhere
     tr.splat_dev(0, 0, vp, W, H, out.data_ptr(), clear=(0.1, 0.2, 0.3, 1.0), stream=s)
     torch.cuda.synchronize()

@@ -886,16 +886,15 @@ extern "C" int trt_splat_dev(trt_ctx* ctx, const trt_point* points, uint64_t n_p
   TRT_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t  st = (hipStream_t)stream;
   SplatScratch sc{};
-  sc.n_bins = splat_bins(W, H, point_size, n_points, ctx->tn);
-  // The binned form reserves room for the worst case, four 12-B records per point (a point on a bin corner) + its 8-B
-  // projection: 56 B per point, against 8 B per PIXEL for the one-pass form.  Beyond 8 GiB of records the one-pass form
-  // is taken instead (its scratch does not grow with the cloud).
-  const size_t np = n_points ? (size_t)n_points : 1;
-  if(sc.n_bins && np * (4 * kSplatRecordSize + 8) > ((size_t)8 << 30)) sc.n_bins = 0;
-  if(sc.n_bins)
+  // The binned forms reserve room for the worst case, four 12-B records per point (a point on a bin corner): the paged form
+  // two pages per bin + a pool for 4n records (8.4 M points, 512 bins: 0.8 GB), the two-pass forms 56 B per point —
+  // against 8 B per PIXEL for the one-pass form, which splat_plan picks beyond 8 GiB of records (its scratch does not grow
+  // with the cloud).
+  sc.plan = splat_plan(W, H, point_size, n_points, ctx->tn);
+  if(sc.plan.mode != kSplatOnePass)
   {
-    // sized for the largest bin count once: the count words and the ticket must be zero between calls — `resolve` and
-    // the last block of `count` leave them so; a call that failed in between marks them dirty
+    // sized for the largest bin count once: the count, state, pool and ticket words must be zero between calls — the
+    // kernels leave them so; a call that failed in between marks them dirty
     if(ctx->d_bins.cap < kSplatBinWords * sizeof(uint32_t))
     {
       if(int rc = grow(ctx, ctx->d_bins, kSplatBinWords * sizeof(uint32_t), st)) return rc;
@@ -906,20 +905,16 @@ extern "C" int trt_splat_dev(trt_ctx* ctx, const trt_point* points, uint64_t n_p
       TRT_HIP(ctx, launch_zero_words((unsigned int*)ctx->d_bins.p, (uint32_t)kSplatBinWords, st));   // a kernel node when captured
       ctx->bins_dirty = false;
     }
-    const size_t proj_bytes  = (np * 8 + 15) & ~(size_t)15, rec_bytes = (np * 4 * kSplatRecordSize + 15) & ~(size_t)15;
-    const size_t table_bytes = sc.n_bins <= kSplatSortBins ? (np / kSplatSortChunk + 4) * sc.n_bins * sizeof(uint32_t) : 0;
-    if(int rc = grow(ctx, ctx->d_recs, proj_bytes + rec_bytes + table_bytes, st)) return rc;
+    if(int rc = grow(ctx, ctx->d_recs, sc.plan.total(), st)) return rc;
     sc.bin_words = (uint32_t*)ctx->d_bins.p;
-    sc.proj      = ctx->d_recs.p;                                    // 8-B aligned
-    sc.records   = (char*)ctx->d_recs.p + proj_bytes;
-    sc.table     = (uint32_t*)((char*)ctx->d_recs.p + proj_bytes + rec_bytes);
+    sc.records   = ctx->d_recs.p;
   }
   else
   {
     if(int rc = grow(ctx, ctx->d_keys, (size_t)W * H * sizeof(unsigned long long), st)) return rc;
     sc.keys = (unsigned long long*)ctx->d_keys.p;
   }
-  if(sc.n_bins) ctx->bins_dirty = true;   // until every kernel of the call is enqueued
+  if(sc.plan.mode != kSplatOnePass) ctx->bins_dirty = true;   // until every kernel of the call is enqueued
   TRT_HIP(ctx, launch_splat(points, n_points, viewProj, W, H, clearColor, point_size, sc, rgba, ctx->n_cus, ctx->tn, st));
   ctx->bins_dirty = false;
   return TRT_OK;

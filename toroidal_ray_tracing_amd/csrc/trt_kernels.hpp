@@ -98,20 +98,29 @@ constexpr int kPersistentBlocksPerCU = 16;  // 4× the resident 4 blocks/CU: the
 
 hipError_t launch_post(const float* in, uint64_t n, float* f32_out, uint8_t* u8_out, int n_cus, const Tuning& tn,
                        hipStream_t stream);
-// Scratch of the re-projection: the binned form (n_bins != 0: kSplatBinWords zero-initialised words + up to
-// 4·n_points 12-B records) or the one-pass form (keys: W·H 64-bit words).
-constexpr size_t kSplatBinWords   = 3 * 8192 + 64;   // count / offset / cursor for the largest bin count, + the ticket word
+// Scratch of the re-projection: the binned form (mode != 0: kSplatBinWords zero-initialised words + the 12-B records of
+// the mode, splat_plan) or the one-pass form (keys: W·H 64-bit words).
+constexpr size_t kSplatBinWords   = 5 * 8192 + 64;   // count / offset / cursor / 64-bit page state for the largest bin count, + the ticket, pool and error words
 constexpr size_t kSplatRecordSize = 12;
 constexpr size_t kSplatSortBins = 2048, kSplatSortChunk = 4096;   // = kSortBins, kSortChunk of trt_kernels.hip
+enum SplatMode { kSplatOnePass = 0, kSplatSorted = 1, kSplatDirect = 2, kSplatPaged = 3 };
+// What a call needs (splat_plan): the form it takes and the bytes of ctx scratch behind `records`, laid out as
+// [records | proj | table | page_bin], every part 16-byte aligned.
+struct SplatPlan {
+  int      mode;        // SplatMode
+  uint32_t n_bins;
+  uint32_t page_shift;  // paged: a page holds 1 << page_shift records
+  uint32_t pool_pages;  // paged: pages behind the bins' first pages
+  size_t   rec_bytes, proj_bytes, table_bytes, pagebin_bytes;
+  size_t   total() const { return rec_bytes + proj_bytes + table_bytes + pagebin_bytes; }
+};
 struct SplatScratch {
-  uint32_t            n_bins;
+  SplatPlan           plan;
   uint32_t*           bin_words;
-  void*               records;   // 12 B x 4 n_points
-  void*               proj;      // 8 B x n_points
-  uint32_t*           table;     // (n_points / 4096 + 1) x n_bins words when n_bins <= 2048 (sorted scatter), else unused
+  void*               records;   // plan.total() bytes
   unsigned long long* keys;
 };
-uint32_t   splat_bins(uint32_t W, uint32_t H, float point_size, uint64_t n_points, const Tuning& tn);   // 0: one-pass form
+SplatPlan  splat_plan(uint32_t W, uint32_t H, float point_size, uint64_t n_points, const Tuning& tn);
 hipError_t launch_splat(const trt_point* pts, uint64_t n_points, const float* vp, uint32_t W, uint32_t H,
                         const float* clear, float point_size, const SplatScratch& sc, float* rgba, int n_cus,
                         const Tuning& tn, hipStream_t stream);
