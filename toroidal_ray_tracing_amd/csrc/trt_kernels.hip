@@ -2046,6 +2046,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void splat_bin_kernel(const trt_po
         }
       }
     }
+    // (belt and braces: a word that adds have pushed out of its poison pattern could name pages that do not exist —
+    // nothing is ever written outside the record area)
+    const uint32_t limit = (2u * b.n_bins + b.pool_pages) << b.page_shift;
+    if(at0 != ~0u && (at0 > limit - first || (first < cj && at1 > limit - (cj - first)))) at0 = ~0u;
     lfirst[k] |= first << 16;
     g0[k]      = at0;
     g1[k]      = at1;
