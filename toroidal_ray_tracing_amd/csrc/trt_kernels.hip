@@ -1870,9 +1870,11 @@ __global__ __launch_bounds__(kSortThreads, 4) void splat_bin_kernel(const trt_po
       pn[u] = chunk < n_chunks && i < f1 ? reinterpret_cast<const float4*>(pts)[2 * i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   };
-  fetch(blockIdx.x);
+  constexpr bool kPrefetch = NB <= 512u;   // (the wider instantiation has four bins per thread to keep: prefetching would spill)
+  if(kPrefetch) fetch(blockIdx.x);
   for(uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
   {
+  if(!kPrefetch) fetch(chunk);
   for(uint32_t k = tid; k < b.n_bins; k += kSortThreads) hist[k] = 0u;
   __syncthreads();   // (also: the previous chunk's write-out has read the staging area and the bins' places)
   const uint64_t i0 = chunk * kSortChunk, i1 = min(n, i0 + kSortChunk);
@@ -1881,7 +1883,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void splat_bin_kernel(const trt_po
     float4 p[kSortPer];
 #pragma unroll
     for(uint32_t u = 0; u < kSortPer; ++u) p[u] = pn[u];
-    fetch(chunk + gridDim.x);
+    if(kPrefetch) fetch(chunk + gridDim.x);
 #pragma unroll
     for(uint32_t u = 0; u < kSortPer; ++u)
     {
