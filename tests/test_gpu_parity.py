@@ -1359,6 +1359,53 @@ def test_splat_bit_exact(tr, oracle):
     assert torch.equal(out, torch.tensor([0.1, 0.2, 0.3, 1.0], device=dev).expand(H, W, 4))
 
 
+def test_reprojection_and_post_in_a_graph(tr, oracle):
+    """trt_splat_dev + trt_post_dev captured into ONE hipGraph once the ctx's scratch is sized and replayed:
+    the bins' words, the page pool and the tickets are left zero by every call, so replays, eager calls with ANOTHER cloud in
+    between and replays again all give the oracle's image — on a cloud crowded enough that bins rotate their page windows."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9)
+    W, H = 512, 256
+    vp = camera.perspective_vk(60, W / H) @ camera.look_at((0.0, 0.5, 5.0), (0, 0, 0))
+
+    def cloud(n, spread):
+        pts = np.zeros((n, 8), np.float32)
+        pts[:, :3] = rng.uniform(-1, 1, (n, 3)) * spread
+        pts[:, 4:7] = rng.uniform(0, 1, (n, 3))
+        pts[n // 2:n // 2 + 1000] = pts[:1000]
+        return pts
+
+    a_np, b_np = cloud(600_000, (0.6, 0.4, 0.3)), cloud(150_000, (2.5, 1.5, 1.0))   # a: 8 bins' worth of a 16-bin image, crowded
+    d_a, d_b = torch.from_numpy(a_np).to(dev), torch.from_numpy(b_np).to(dev)
+    img = torch.empty(H, W, 4, device=dev)
+    out8 = torch.empty(H, W, 4, dtype=torch.uint8, device=dev)
+    want_a = oracle.splat(a_np, vp, W, H)
+    want_b = oracle.splat(b_np, vp, W, H)
+    _, want_a8 = oracle.post(want_a)
+    cur = torch.cuda.current_stream()
+    tr.splat_dev(d_a.data_ptr(), len(a_np), vp, W, H, img.data_ptr(), stream=cur.cuda_stream)      # sizes the scratch
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(img.cpu().numpy().view(np.uint32), want_a.view(np.uint32))
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side), torch.cuda.graph(gr, stream=side):
+        tr.splat_dev(d_a.data_ptr(), len(a_np), vp, W, H, img.data_ptr(), stream=side.cuda_stream)
+        tr.post_dev(img.data_ptr(), W * H, 0, out8.data_ptr(), stream=side.cuda_stream)
+    cur.wait_stream(side)
+    for k in range(4):
+        img.zero_(); out8.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(img.cpu().numpy().view(np.uint32), want_a.view(np.uint32), err_msg=f"replay {k}")
+        np.testing.assert_array_equal(out8.cpu().numpy(), want_a8)
+        if k == 1:   # an eager call with another (smaller: nothing has to grow) cloud between two replays
+            tr.splat_dev(d_b.data_ptr(), len(b_np), vp, W, H, img.data_ptr(), stream=cur.cuda_stream)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(img.cpu().numpy().view(np.uint32), want_b.view(np.uint32))
+
+
 def test_capture_then_reproject(tr, oracle):
     """The research pipeline end to end: toroidal capture (RenderedData pos + colour) ->
     Point cloud (createCloudDataBuffer: pos.w = color.w = 0) -> re-projection from a pinhole
