@@ -10,7 +10,11 @@ import numpy as np
 import torch
 from toroidal_ray_tracing_amd import camera
 from toroidal_ray_tracing_amd.tracer import Tracer
-z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_aimed_ev.npz"))
+_ev = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_aimed_ev.npz")
+if not os.path.exists(_ev):   # (not shipped to the GPU box: a few seconds of CPU)
+    import subprocess
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "make_aimed_ev.py")], check=True)
+z = np.load(_ev)
 o, d, ev = z["o"], z["d"], z["ev"]
 n = len(ev)
 dev = torch.device("cuda:0"); tr = Tracer(0); s = torch.cuda.current_stream()
