@@ -481,3 +481,35 @@ def test_shading_chain_vs_independent_fp64(name, cam):
     assert primary == q["primary"] * n_t == W * H * n_t
     assert abs(bounce - q["bounce"] * n_t) <= slack * n_t
     assert q["shadow"] - slack <= shadow <= (q["shadow"] + slack) * n_t
+
+
+@pytest.mark.parametrize("scene", [0, 1, 2])
+def test_enclosure_cull_vs_independent_fp64(oracle, scene):
+    """The oracle WITH its enclosure cull against oracle/truth.py::shade_frame — which tests every torus in every query and shares
+    no arithmetic with the oracle — on nests seen from outside, from close by, from between two shells and from above the hole:
+    hit/miss and the torus hit agree on every robust pixel, colours to 1e-4 (what a wrongly skipped shell would break)."""
+    from oracle import truth
+    P, M = camera.PLASTIC, camera.MIRROR
+    scenes = [camera.nested_tori_scene(),
+              abi.Scene([((0, 0, 0), 1.0, 0.4, 1), ((0, 0, 0), 1.05, 0.3, 0), ((0, 0.05, 0), 0.97, 0.2, 1), ((0, 0, 0), 1.0, 0.1, 0),
+                         ((2.5, 0, 0), 0.6, 0.2, 1), ((2.5, 0, 0), 0.6, 0.1, 0)], [P, M]),
+              abi.Scene([((0, 0, 0), 2.0, 1.2, 1), ((0, 0, 0), 2.0, 0.5, 1), ((0, 0, 0), 2.0, 0.2, 0)], [P, M])]
+    sc = scenes[scene]
+    W = H = 40
+    mats = [dict(ambient=tuple(m.ambient), diffuse=tuple(m.diffuse), specular=tuple(m.specular), shininess=m.shininess, illum=m.illum)
+            for m in sc._mats]
+    mat4 = lambda a: np.array(a[:], np.float64).reshape(4, 4).T
+    checked = 0
+    for eye in [(0.0, 1.5, -4.0), (0.0, 0.2, -2.9), (2.9, 0.0, 0.0) if scene == 2 else (1.1, 0.0, 0.0), (0.3, 2.5, 0.4)]:
+        g = camera.globals_for(eye, (0.0, 0.0, 0.0), W, H)
+        pc = abi.make_push(max_depth=4)
+        push = dict(clearColor=pc.clearColor[:], lightPosition=pc.lightPosition[:], lightIntensity=pc.lightIntensity,
+                    lightType=pc.lightType, maxDepth=pc.maxDepth, rho=pc.rho)
+        want, robust, _ = truth.shade_frame(sc.tori_list(), mats, mat4(g.viewInverse), mat4(g.projInverse), g.center[:], push, W, H, 0)
+        got, hits, _, _ = oracle.render(sc, g, pc, W, H, abi.TRT_CAMERA_PINHOLE, precision=abi.TRT_SOLVE_F64, nthreads=4)
+        got = got.astype(np.float64)
+        rel = (np.abs(got - want) / (np.abs(want) + 1e-5)).max(axis=-1)[robust]
+        assert robust.mean() > 0.8   # (an eye between two mirror shells sees grazing paths on more pixels than one outside)
+        assert (rel <= 1e-4).mean() >= 0.998 and rel.max() <= 2e-3, (scene, eye, rel.max(), int((rel > 1e-4).sum()))
+        checked += int(robust.sum())
+    assert checked > 4 * W * H * 0.85
